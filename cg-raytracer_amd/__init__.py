@@ -1,0 +1,326 @@
+"""cg-raytracer_amd: MI355X-native BVH traversal + ray/triangle intersection (the hot path of
+mgokbulut/CG-RayTracer) behind a C-ABI (include/cgrt.h).
+
+This module is the thin Python host used by tests/ and bench.py: a ctypes binding of ``libcgrt.so``
+(built in-tree by ``build_native()`` / ``__graft_entry__.build()``).  There is no CPU fallback: if the
+library is missing, or no HIP device is usable, calls raise.
+
+The directory name contains a hyphen, so it is loaded under the module name ``cg_raytracer_amd``
+(see ``__graft_entry__.load_package``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import scenes  # noqa: F401  (re-export)
+from .scenes import SceneData
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcgrt.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+NO_PRIM = 0xFFFFFFFF
+
+RAY_DTYPE = np.dtype([("origin", np.float32, 3), ("direction", np.float32, 3), ("t", np.float32)])
+HIT_DTYPE = np.dtype([("t", np.float32), ("prim_id", np.uint32), ("material_id", np.int32), ("hit", np.uint32)])
+assert RAY_DTYPE.itemsize == 28 and HIT_DTYPE.itemsize == 16
+
+
+class CgrtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"cgrt error {code}: {msg}")
+        self.code = code
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64),
+        ("inner_visits", C.c_uint64),
+        ("leaf_visits", C.c_uint64),
+        ("tri_tests", C.c_uint64),
+        ("sub_visits", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("look_at", C.c_float * 3),
+        ("euler", C.c_float * 3),
+        ("distance", C.c_float),
+        ("fovy", C.c_float),
+        ("aspect", C.c_float),
+    ]
+
+    @staticmethod
+    def from_array(a) -> "Camera":
+        a = np.asarray(a, np.float32)
+        cam = Camera()
+        cam.look_at[:] = a[0:3]
+        cam.euler[:] = a[3:6]
+        cam.distance, cam.fovy, cam.aspect = float(a[6]), float(a[7]), float(a[8])
+        return cam
+
+
+def build_native(verbose: bool = False) -> str:
+    """Compile libcgrt.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError("building libcgrt.so failed")
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/cgrt.h declares
+EXPORTS = [
+    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
+    "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_count_primary", "cgrt_count_batch", "cgrt_record_sizes",
+    "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
+    "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
+]  # fmt: skip
+
+
+def lib() -> C.CDLL:
+    """Load libcgrt.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.cgrt_last_error.restype = C.c_char_p
+    L.cgrt_version.restype = C.c_char_p
+    L.cgrt_scene_create.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, i32, C.POINTER(vp)]
+    L.cgrt_scene_destroy.argtypes = [vp]
+    L.cgrt_scene_destroy.restype = None
+    for f in (L.cgrt_num_levels, L.cgrt_num_nodes):
+        f.argtypes = [vp]
+    L.cgrt_get_nodes.argtypes = [vp, vp, vp]
+    L.cgrt_leaf_prims.argtypes = [vp, i32, vp, u32]
+    L.cgrt_leaf_prims.restype = C.c_int64
+    L.cgrt_build_seconds.argtypes = [vp]
+    L.cgrt_build_seconds.restype = C.c_double
+    L.cgrt_device_bytes.argtypes = [vp]
+    L.cgrt_device_bytes.restype = u64
+    L.cgrt_intersect_batch.argtypes = [vp, vp, u64, vp, vp]
+    L.cgrt_intersect_batch_device.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.cgrt_trace_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp]
+    L.cgrt_trace_primary_device.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp, vp]
+    L.cgrt_generate_rays.argtypes = [vp, C.POINTER(Camera)] + [i32] * 6 + [vp]
+    L.cgrt_count_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [C.POINTER(Counters)]
+    L.cgrt_count_batch.argtypes = [vp, vp, u64, C.POINTER(Counters)]
+    L.cgrt_record_sizes.argtypes = [C.POINTER(u32)] * 4
+    L.cgrt_record_sizes.restype = None
+    L.cgrt_ray_triangle_batch.argtypes = [i32, vp, vp, u64, vp, vp, vp]
+    L.cgrt_ray_plane_batch.argtypes = [i32, vp, vp, u64, vp, vp]
+    L.cgrt_ray_box_batch.argtypes = [i32, vp, vp, u64, vp, vp, vp]
+    L.cgrt_ray_sphere_batch.argtypes = [i32, vp, vp, u64, vp, vp, vp]
+    L.cgrt_triangle_plane_batch.argtypes = [i32, vp, u64, vp]
+    L.cgrt_point_in_triangle_batch.argtypes = [i32, vp, u64, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise CgrtError(rc, lib().cgrt_last_error().decode())
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, np.float32).reshape(shape))
+
+
+def as_rays(origin, direction, t=None) -> np.ndarray:
+    o = np.asarray(origin, np.float32).reshape(-1, 3)
+    d = np.asarray(direction, np.float32).reshape(-1, 3)
+    r = np.zeros(len(o), RAY_DTYPE)
+    r["origin"], r["direction"] = o, d
+    r["t"] = np.float32(np.finfo(np.float32).max) if t is None else np.asarray(t, np.float32)
+    return r
+
+
+def record_sizes() -> dict:
+    v = [C.c_uint32() for _ in range(4)]
+    lib().cgrt_record_sizes(*[C.byref(x) for x in v])
+    return dict(zip(("node", "tri", "sub", "hit"), (int(x.value) for x in v)))
+
+
+def device_count() -> int:
+    return int(lib().cgrt_device_count())
+
+
+class Scene:
+    """Owns a CgrtScene: the host mirror of ``BoundingVolumeHierarchy(Scene*)`` (bvh.h:39-48)."""
+
+    def __init__(self, sd: SceneData, device: int = 0):
+        self.sd = sd
+        self._h = C.c_void_p()
+        pn = _f32(sd.pos_nrm, (-1, 6))
+        tri = np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+        tm = np.ascontiguousarray(sd.tri_mesh, np.uint32)
+        mats = _f32(sd.materials, (-1, 8))
+        sph = _f32(sd.spheres, (-1, 5))
+        _check(
+            lib().cgrt_scene_create(
+                _ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(sph) if len(sph) else None,
+                len(sph), device, C.byref(self._h),
+            )
+        )  # fmt: skip
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            lib().cgrt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    # ---- introspection ----
+    def num_levels(self) -> int:
+        return int(lib().cgrt_num_levels(self._h))
+
+    def build_seconds(self) -> float:
+        return float(lib().cgrt_build_seconds(self._h))
+
+    def device_bytes(self) -> int:
+        return int(lib().cgrt_device_bytes(self._h))
+
+    def nodes(self) -> Tuple[np.ndarray, np.ndarray]:
+        n = int(lib().cgrt_num_nodes(self._h))
+        meta = np.zeros((n, 5), np.int32)
+        boxes = np.zeros((n, 6), np.float32)
+        if n:
+            _check(lib().cgrt_get_nodes(self._h, _ptr(meta), _ptr(boxes)))
+        return meta, boxes
+
+    def leaf_prims(self, node: int) -> np.ndarray:
+        n = int(lib().cgrt_leaf_prims(self._h, node, None, 0))
+        out = np.zeros(n, np.uint32)
+        if n:
+            lib().cgrt_leaf_prims(self._h, node, _ptr(out), n)
+        return out
+
+    # ---- hot path ----
+    def intersect(self, rays: np.ndarray, want_normals: bool = True):
+        """Batched BoundingVolumeHierarchy::intersect. Returns (hits[HIT_DTYPE], normals or None)."""
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        normals = np.zeros((len(rays), 3), np.float32) if want_normals else None
+        _check(lib().cgrt_intersect_batch(self._h, _ptr(rays), len(rays), _ptr(hits), _ptr(normals)))
+        return hits, normals
+
+    def trace_primary(self, cam, W: int, H: int, rect=None, rank: int = 0, nranks: int = 1, want_normals: bool = False):
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
+        hits = np.zeros(W * H, HIT_DTYPE)
+        hits["prim_id"] = NO_PRIM
+        hits["material_id"] = -1
+        hits["t"] = np.nan  # pixels this call does not own stay marked
+        normals = np.zeros((W * H, 3), np.float32) if want_normals else None
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_trace_primary(self._h, C.byref(c), W, H, x0, y0, x1, y1, rank, nranks, _ptr(hits), _ptr(normals)))
+        return hits, normals
+
+    def trace_primary_device(self, cam, W, H, d_hits_ptr: int, rect=None, rank=0, nranks=1, d_normals_ptr: int = 0, stream: int = 0):
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(
+            lib().cgrt_trace_primary_device(
+                self._h, C.byref(c), W, H, x0, y0, x1, y1, rank, nranks, C.c_void_p(d_hits_ptr),
+                C.c_void_p(d_normals_ptr) if d_normals_ptr else None, C.c_void_p(stream) if stream else None,
+            )
+        )  # fmt: skip
+
+    def intersect_device(self, d_rays_ptr: int, n: int, d_hits_ptr: int, d_normals_ptr: int = 0, stream: int = 0):
+        _check(
+            lib().cgrt_intersect_batch_device(
+                self._h, C.c_void_p(d_rays_ptr), n, C.c_void_p(d_hits_ptr), C.c_void_p(d_normals_ptr) if d_normals_ptr else None,
+                C.c_void_p(stream) if stream else None,
+            )
+        )  # fmt: skip
+
+    def generate_rays(self, cam, W: int, H: int, rect=None) -> np.ndarray:
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
+        rays = np.zeros((x1 - x0) * (y1 - y0), RAY_DTYPE)
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_generate_rays(self._h, C.byref(c), W, H, x0, y0, x1, y1, _ptr(rays)))
+        return rays
+
+    def count_primary(self, cam, W, H, rect=None, rank=0, nranks=1) -> dict:
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        out = Counters()
+        _check(lib().cgrt_count_primary(self._h, C.byref(c), W, H, x0, y0, x1, y1, rank, nranks, C.byref(out)))
+        return out.as_dict()
+
+    def count_batch(self, rays: np.ndarray) -> dict:
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        out = Counters()
+        _check(lib().cgrt_count_batch(self._h, _ptr(rays), len(rays), C.byref(out)))
+        return out.as_dict()
+
+
+# ---- element-wise primitives (src/ray_tracing.h:10-20) ----
+def ray_triangle(tri18, rays, device=0):
+    tri18 = _f32(tri18, (-1, 18))
+    rays = np.ascontiguousarray(rays, RAY_DTYPE)
+    n = len(rays)
+    t, hit, nrm = np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros((n, 3), np.float32)
+    _check(lib().cgrt_ray_triangle_batch(device, _ptr(tri18), _ptr(rays), n, _ptr(t), _ptr(hit), _ptr(nrm)))
+    return t, hit, nrm
+
+
+def ray_plane(plane4, rays, device=0):
+    plane4 = _f32(plane4, (-1, 4))
+    rays = np.ascontiguousarray(rays, RAY_DTYPE)
+    n = len(rays)
+    t, hit = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+    _check(lib().cgrt_ray_plane_batch(device, _ptr(plane4), _ptr(rays), n, _ptr(t), _ptr(hit)))
+    return t, hit
+
+
+def ray_box(box6, rays, device=0):
+    box6 = _f32(box6, (-1, 6))
+    rays = np.ascontiguousarray(rays, RAY_DTYPE)
+    n = len(rays)
+    t, hit, inside = np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    _check(lib().cgrt_ray_box_batch(device, _ptr(box6), _ptr(rays), n, _ptr(t), _ptr(hit), _ptr(inside)))
+    return t, hit, inside
+
+
+def ray_sphere(sph4, rays, device=0):
+    sph4 = _f32(sph4, (-1, 4))
+    rays = np.ascontiguousarray(rays, RAY_DTYPE)
+    n = len(rays)
+    t, hit, nrm = np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros((n, 3), np.float32)
+    _check(lib().cgrt_ray_sphere_batch(device, _ptr(sph4), _ptr(rays), n, _ptr(t), _ptr(hit), _ptr(nrm)))
+    return t, hit, nrm
+
+
+def triangle_plane(tri9, device=0):
+    tri9 = _f32(tri9, (-1, 9))
+    out = np.zeros((len(tri9), 4), np.float32)
+    _check(lib().cgrt_triangle_plane_batch(device, _ptr(tri9), len(tri9), _ptr(out)))
+    return out
+
+
+def point_in_triangle(in15, device=0):
+    in15 = _f32(in15, (-1, 15))
+    out = np.zeros(len(in15), np.uint8)
+    _check(lib().cgrt_point_in_triangle_batch(device, _ptr(in15), len(in15), _ptr(out)))
+    return out

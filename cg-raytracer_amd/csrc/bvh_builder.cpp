@@ -1,0 +1,264 @@
+// bvh_builder.cpp -- the reference's BVH construction (src/bounding_volume_hierarchy.cpp:42-76,
+// :88-134, :168-207, :235-372) on a flat layout.
+//
+// The reference deep-copies every vertex of a mesh into every node (bvh.cpp:205-206) and so cannot
+// build dragon-sized scenes.  Here one permutation array `order` holds the primitive
+// ids; every node owns a contiguous range of it, subdivided into "runs" (one per reference Mesh held
+// by the node).  What is kept exactly, because traversal results depend on it:
+//   * split axis rule (:289), median split at size()/2 with the middle element going right (:201-202),
+//   * libstdc++ std::sort with the same comparison outcomes => same order among equal keys,
+//   * mesh-list split for multi-mesh nodes, keyed by each mesh's median-triangle centroid (:88-110),
+//   * child boxes over triangle-referenced vertices only (:235-268),
+//   * leaf rule: level 11, or one mesh with one triangle (:320-322), breadth-first numbering (:343-372).
+#include "bvh_builder.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <utility>
+
+#include "cgrt_math.h"
+
+namespace cgrt {
+namespace {
+
+struct Run {
+    int mesh;
+    uint32_t first, count;  // sub-range of `order`
+};
+
+struct Builder {
+    const HostScene& sc;
+    std::vector<uint32_t>& order;
+    std::vector<float> cen[3];  // per-prim centroid coordinate per axis (bvh.cpp:126)
+
+    Builder(const HostScene& s, std::vector<uint32_t>& ord) : sc(s), order(ord) {}
+
+    const float* vpos(uint32_t v) const { return &sc.pos_nrm[6 * (size_t)v]; }
+
+    void centroids() {
+        for (int a = 0; a < 3; a++) cen[a].resize(sc.ntris);
+        for (uint32_t p = 0; p < sc.ntris; p++) {
+            const float *A = vpos(sc.tri[3 * p]), *B = vpos(sc.tri[3 * p + 1]), *C = vpos(sc.tri[3 * p + 2]);
+            for (int a = 0; a < 3; a++) cen[a][p] = ((A[a] + B[a]) + C[a]) / 3.0f;
+        }
+    }
+
+    // std::sort of order[first, first+count) by centroid coordinate (bvh.cpp:122-134).  Sorting
+    // (key, id) pairs with a key-only comparator makes libstdc++'s introsort take the same
+    // decisions, hence the same permutation, as sorting the ids with the reference's comparator.
+    void sort_range(uint32_t first, uint32_t count, int axis, std::vector<std::pair<float, uint32_t>>& tmp) {
+        tmp.resize(count);
+        const std::vector<float>& key = cen[axis];
+        for (uint32_t i = 0; i < count; i++) tmp[i] = std::make_pair(key[order[first + i]], order[first + i]);
+        std::sort(tmp.begin(), tmp.end(),
+                  [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
+        for (uint32_t i = 0; i < count; i++) order[first + i] = tmp[i].second;
+    }
+
+    Box6 bounds(uint32_t first, uint32_t count) const {  // bvh.cpp:235-268
+        // :238 routes the first vertex index through a float
+        float fi = (float)sc.tri[3 * (size_t)order[first]];
+        const float* f = vpos((uint32_t)(size_t)fi);
+        float mn[3] = {f[0], f[1], f[2]}, mx[3] = {f[0], f[1], f[2]};
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t p = order[first + i];
+            for (int k = 0; k < 3; k++) {
+                const float* v = vpos(sc.tri[3 * (size_t)p + k]);
+                for (int a = 0; a < 3; a++) {
+                    mn[a] = (v[a] < mn[a]) ? v[a] : mn[a];
+                    mx[a] = (v[a] > mx[a]) ? v[a] : mx[a];
+                }
+            }
+        }
+        Box6 b;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = mn[a];
+            b.hi[a] = mx[a];
+        }
+        return b;
+    }
+};
+
+}  // namespace
+
+bool build_reference_bvh(const HostScene& sc, BuiltBvh& out, std::string& err) {
+    auto t_start = std::chrono::steady_clock::now();
+    out = BuiltBvh();
+    // ---- validation (the reference has none; out-of-range input would be UB there) ----
+    if (sc.pos_nrm.size() != 6 * (size_t)sc.nverts || sc.tri.size() != 3 * (size_t)sc.ntris ||
+        sc.tri_mesh.size() != sc.ntris || sc.materials.size() != 8 * (size_t)sc.nmesh ||
+        sc.spheres.size() != 5 * (size_t)sc.nspheres) {
+        err = "scene arrays do not match their counts";
+        return false;
+    }
+    for (uint32_t p = 0; p < sc.ntris; p++) {
+        if (sc.tri[3 * p] >= sc.nverts || sc.tri[3 * p + 1] >= sc.nverts || sc.tri[3 * p + 2] >= sc.nverts) {
+            err = "triangle " + std::to_string(p) + " references a vertex out of range";
+            return false;
+        }
+        if (sc.tri_mesh[p] >= sc.nmesh || (p > 0 && sc.tri_mesh[p] < sc.tri_mesh[p - 1])) {
+            err = "tri_mesh must be non-decreasing and < nmesh";
+            return false;
+        }
+    }
+    for (uint32_t s = 0; s < sc.nspheres; s++)
+        out.spheres.push_back(SphereRecord{{sc.spheres[5 * s], sc.spheres[5 * s + 1], sc.spheres[5 * s + 2]}, sc.spheres[5 * s + 3]});
+
+    if (sc.ntris == 0) {  // bvh.cpp:52-55: no meshes -> no tree; intersect() then only tests spheres (:870)
+        out.levels = 1;  // numLevels() of an empty node list returns 0 + 1 (:214-224)
+        out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        return true;
+    }
+
+    out.order.resize(sc.ntris);
+    for (uint32_t p = 0; p < sc.ntris; p++) out.order[p] = p;
+    Builder B(sc, out.order);
+    B.centroids();
+
+    // runs[i] is only meaningful while node i is waiting to be split
+    std::vector<std::vector<Run>> runs;
+    {
+        std::vector<Run> r;
+        uint32_t p = 0;
+        while (p < sc.ntris) {
+            uint32_t q = p;
+            while (q < sc.ntris && sc.tri_mesh[q] == sc.tri_mesh[p]) q++;
+            r.push_back(Run{(int)sc.tri_mesh[p], p, q - p});
+            p = q;
+        }
+        bool leaf = (MAX_LEVELS - 1 == 0) || (r.size() == 1 && r[0].count == 1);  // bvh.cpp:59
+        out.nodes.push_back(TopoNode{leaf, 0, B.bounds(0, sc.ntris), {-1, -1}, 0, sc.ntris});
+        runs.push_back(std::move(r));
+    }
+
+    std::vector<std::pair<float, uint32_t>> tmp;
+    std::vector<uint32_t> scratch;
+    for (size_t i = 0; i < out.nodes.size(); i++) {  // createTree, bvh.cpp:343-372
+        if (out.nodes[i].leaf) continue;
+        const TopoNode nd = out.nodes[i];
+        std::vector<Run> my = std::move(runs[i]);
+        const float ex = nd.box.hi[0] - nd.box.lo[0], ey = nd.box.hi[1] - nd.box.lo[1], ez = nd.box.hi[2] - nd.box.lo[2];
+        const int axis = (ex > ey) ? ((ex > ez) ? 0 : 2) : ((ey > ez) ? 1 : 2);  // :289
+
+        std::vector<Run> lr, rr;
+        uint32_t lcount;
+        if (my.size() > 1) {
+            // bvh.cpp:168-179 / :88-110: order the MESHES by the centroid coordinate of the median
+            // triangle of each mesh's sorted triangle list, then split the mesh list in half.
+            struct Keyed {
+                float key;
+                Run run;
+            };
+            std::vector<Keyed> ks;
+            for (const Run& r : my) {
+                scratch.assign(out.order.begin() + r.first, out.order.begin() + r.first + r.count);
+                std::vector<std::pair<float, uint32_t>> kv(r.count);
+                for (uint32_t k = 0; k < r.count; k++) kv[k] = std::make_pair(B.cen[axis][scratch[k]], scratch[k]);
+                std::sort(kv.begin(), kv.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
+                    return a.first < b.first;
+                });
+                ks.push_back(Keyed{kv[r.count / 2].first, r});
+            }
+            std::sort(ks.begin(), ks.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+            // rewrite this node's range of `order` in the new mesh order (triangle order inside a mesh is kept)
+            scratch.assign(out.order.begin() + nd.first, out.order.begin() + nd.first + nd.count);
+            uint32_t w = nd.first;
+            const size_t half = ks.size() / 2;
+            for (size_t k = 0; k < ks.size(); k++) {
+                const Run& r = ks[k].run;
+                std::memcpy(&out.order[w], &scratch[r.first - nd.first], sizeof(uint32_t) * r.count);
+                (k < half ? lr : rr).push_back(Run{r.mesh, w, r.count});
+                w += r.count;
+            }
+            lcount = 0;
+            for (const Run& r : lr) lcount += r.count;
+        } else {
+            // bvh.cpp:192-207: one mesh -> sort its triangles along the axis, left = [0, n/2)
+            B.sort_range(nd.first, nd.count, axis, tmp);
+            lcount = nd.count / 2;
+            lr.push_back(Run{my[0].mesh, nd.first, lcount});
+            rr.push_back(Run{my[0].mesh, nd.first + lcount, nd.count - lcount});
+        }
+        const bool lvl = (nd.level + 1 == MAX_LEVELS - 1);  // :320
+        const bool ll = lvl || (lr.size() == 1 && lr[0].count == 1);
+        const bool rl = lvl || (rr.size() == 1 && rr[0].count == 1);
+        const int li = (int)out.nodes.size();
+        out.nodes[i].child[0] = li;
+        out.nodes[i].child[1] = li + 1;
+        out.nodes.push_back(TopoNode{ll, nd.level + 1, B.bounds(nd.first, lcount), {-1, -1}, nd.first, lcount});
+        out.nodes.push_back(
+            TopoNode{rl, nd.level + 1, B.bounds(nd.first + lcount, nd.count - lcount), {-1, -1}, nd.first + lcount, nd.count - lcount});
+        runs.push_back(std::move(lr));
+        runs.push_back(std::move(rr));
+    }
+
+    int maxLevel = 0;
+    for (const TopoNode& n : out.nodes) maxLevel = std::max(maxLevel, n.level);
+    out.levels = maxLevel + 1;
+    if (out.levels > MAX_LEVELS) {
+        err = "BVH deeper than 12 levels";
+        return false;
+    }
+
+    // ---- flatten ----
+    out.node_to_ref_index.assign(out.nodes.size(), -1);
+    uint32_t npk = 0, nlf = 0;
+    for (size_t i = 0; i < out.nodes.size(); i++) out.node_to_ref_index[i] = out.nodes[i].leaf ? (int)nlf++ : (int)npk++;
+    out.packets.resize(npk);
+    out.leaves.resize(nlf);
+    out.tris.resize(sc.ntris);
+    out.tri_normals.resize(sc.ntris);
+    auto ref_of = [&](int node) -> uint32_t {
+        return out.nodes[node].leaf ? (REF_LEAF | (uint32_t)out.node_to_ref_index[node]) : (uint32_t)out.node_to_ref_index[node];
+    };
+    uint32_t w = 0;
+    for (size_t i = 0; i < out.nodes.size(); i++) {
+        const TopoNode& n = out.nodes[i];
+        if (n.leaf) {
+            LeafRec& L = out.leaves[out.node_to_ref_index[i]];
+            L.first = w;
+            L.count = n.count;
+            L.sub_root = REF_NONE;
+            L.pad = 0;
+            for (uint32_t k = 0; k < n.count; k++, w++) {
+                const uint32_t p = out.order[n.first + k];
+                const float* a = B.vpos(sc.tri[3 * (size_t)p]);
+                const float* b = B.vpos(sc.tri[3 * (size_t)p + 1]);
+                const float* c = B.vpos(sc.tri[3 * (size_t)p + 2]);
+                TriRecord& T = out.tris[w];
+                std::memcpy(T.v0, a, 12);
+                std::memcpy(T.v1, b, 12);
+                std::memcpy(T.v2, c, 12);
+                F3 pn;
+                float D;
+                triangle_plane(f3(a[0], a[1], a[2]), f3(b[0], b[1], b[2]), f3(c[0], c[1], c[2]), pn, D);
+                T.n[0] = pn.x;
+                T.n[1] = pn.y;
+                T.n[2] = pn.z;
+                T.D = D;
+                T.prim_id = p;
+                T.mesh_id = sc.tri_mesh[p];
+                T.pad = 0;
+                TriNormals& N = out.tri_normals[w];
+                std::memcpy(N.n1, a + 3, 12);
+                std::memcpy(N.n2, b + 3, 12);
+                std::memcpy(N.n3, c + 3, 12);
+            }
+        } else {
+            NodePacket& P = out.packets[out.node_to_ref_index[i]];
+            const TopoNode &l = out.nodes[n.child[0]], &r = out.nodes[n.child[1]];
+            std::memcpy(P.lbox, &l.box, 24);
+            std::memcpy(P.rbox, &r.box, 24);
+            P.left = ref_of(n.child[0]);
+            P.right = ref_of(n.child[1]);
+            P.pad[0] = P.pad[1] = 0;
+        }
+    }
+    out.root_box = out.nodes[0].box;
+    out.root_ref = ref_of(0);
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return true;
+}
+
+}  // namespace cgrt

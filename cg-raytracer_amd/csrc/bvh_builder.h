@@ -1,0 +1,50 @@
+// bvh_builder.h -- host-side construction of the reference's BVH (topology + leaf order) on a flat
+// layout, and its flattening into the device records of cgrt_layout.h.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "cgrt_layout.h"
+
+namespace cgrt {
+
+struct HostScene {
+    std::vector<float> pos_nrm;      // nverts x 6
+    std::vector<uint32_t> tri;       // ntris x 3 (global vertex indices)
+    std::vector<uint32_t> tri_mesh;  // ntris
+    std::vector<float> materials;    // nmesh x 8
+    std::vector<float> spheres;      // nspheres x 5
+    uint32_t nverts = 0, ntris = 0, nmesh = 0, nspheres = 0;
+};
+
+// A node of the reference tree.  Its triangles are order[first .. first+count), already in the order
+// intersectLeaf would scan them (mesh runs in node order, triangles in run order).
+struct TopoNode {
+    bool leaf;
+    int level;
+    Box6 box;
+    int child[2];
+    uint32_t first, count;
+};
+
+struct BuiltBvh {
+    std::vector<TopoNode> nodes;    // level order, children adjacent (bvh.cpp:358-364)
+    std::vector<uint32_t> order;    // prim ids; every node owns a contiguous range
+    int levels = 0;
+    // device-side flattening
+    std::vector<NodePacket> packets;
+    std::vector<LeafRec> leaves;
+    std::vector<int> node_to_ref_index;  // node -> packet index (inner) or leaf index (leaf)
+    std::vector<TriRecord> tris;         // leaf order
+    std::vector<TriNormals> tri_normals;
+    std::vector<SphereRecord> spheres;
+    Box6 root_box{};
+    uint32_t root_ref = REF_NONE;
+    double build_seconds = 0;
+};
+
+// Returns false and sets err on invalid input.
+bool build_reference_bvh(const HostScene& scene, BuiltBvh& out, std::string& err);
+
+}  // namespace cgrt

@@ -1,0 +1,491 @@
+// capi.cpp -- implementation of the C-ABI declared in include/cgrt.h.
+// Host C++ over the HIP runtime; no torch types, no CPU traversal path: every intersect/trace entry
+// launches the gfx950 kernels of trace_kernels.hip and fails loudly when no device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cgrt.h"
+#include "bvh_builder.h"
+#include "cgrt_layout.h"
+#include "cgrt_math.h"
+#include "trace_kernels.h"
+
+using namespace cgrt;
+
+static_assert(sizeof(CgrtRay) == 28, "CgrtRay must match the reference Ray (ray.h:9-13)");
+static_assert(sizeof(CgrtHit) == sizeof(CgrtHitDev), "CgrtHit layout");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return CGRT_E_HIP;
+}
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+// RAII device buffer for the host-pointer convenience entries.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+int select_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(CGRT_E_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e) + ")");
+    if (device < 0 || device >= n) return fail(CGRT_E_NO_DEVICE, "device index " + std::to_string(device) + " out of range");
+    HIP_TRY(hipSetDevice(device));
+    return CGRT_OK;
+}
+
+// Ray-independent part of Trackball::generateRay / position (trackball.cpp:70-73, :92-103),
+// glm::qua(eulerAngles) as in glm 0.9.9.8 type_quat.inl.
+CameraDev make_camera(const CgrtCamera& c) {
+    const float hx = c.euler[0] * 0.5f, hy = c.euler[1] * 0.5f, hz = c.euler[2] * 0.5f;
+    const float cx = std::cos(hx), cy = std::cos(hy), cz = std::cos(hz);
+    const float sx = std::sin(hx), sy = std::sin(hy), sz = std::sin(hz);
+    Q4 q;
+    q.w = cx * cy * cz + sx * sy * sz;
+    q.x = sx * cy * cz - cx * sy * sz;
+    q.y = cx * sy * cz + sx * cy * sz;
+    q.z = cx * cy * sz - sx * sy * cz;
+    const F3 p = add(f3(c.look_at[0], c.look_at[1], c.look_at[2]), quat_rotate(q, f3(0.0f, 0.0f, -c.distance)));
+    CameraDev d;
+    d.pos[0] = p.x;
+    d.pos[1] = p.y;
+    d.pos[2] = p.z;
+    d.q[0] = q.w;
+    d.q[1] = q.x;
+    d.q[2] = q.y;
+    d.q[3] = q.z;
+    d.half_h = std::tan(c.fovy / 2.0f);
+    d.half_w = c.aspect * d.half_h;
+    return d;
+}
+
+bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nranks, FrameDev& F) {
+    if (W <= 0 || H <= 0 || x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1 || nranks <= 0 || rank < 0 || rank >= nranks)
+        return false;
+    F.W = W;
+    F.H = H;
+    F.x0 = x0;
+    F.y0 = y0;
+    F.x1 = x1;
+    F.y1 = y1;
+    F.tiles_x = (x1 - x0 + 7) / 8;
+    F.tiles_y = (y1 - y0 + 7) / 8;
+    F.rank = rank;
+    F.nranks = nranks;
+    const uint64_t nt = (uint64_t)F.tiles_x * (uint64_t)F.tiles_y;
+    F.ntiles_rank = (uint32_t)((nt + (uint64_t)nranks - 1 - (uint64_t)rank) / (uint64_t)nranks);
+    return true;
+}
+
+}  // namespace
+
+struct CgrtScene {
+    int device = 0;
+    BuiltBvh bvh;
+    uint32_t ntris = 0;
+    SceneDev dev{};
+    void* d_packets = nullptr;
+    void* d_leaves = nullptr;
+    void* d_tris = nullptr;
+    void* d_tri_normals = nullptr;
+    void* d_spheres = nullptr;
+    unsigned long long* d_counters = nullptr;
+    uint64_t device_bytes = 0;
+    ~CgrtScene() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        for (void* p : {d_packets, d_leaves, d_tris, d_tri_normals, d_spheres, (void*)d_counters})
+            if (p) (void)hipFree(p);
+    }
+};
+
+namespace {
+template <class T>
+int upload(const std::vector<T>& v, void** dptr, uint64_t& total) {
+    const size_t bytes = v.size() * sizeof(T);
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice));
+    total += bytes;
+    return CGRT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* cgrt_last_error(void) { return g_err.c_str(); }
+const char* cgrt_version(void) { return "cgrt-mi355x 0.1 (gfx950)"; }
+
+int cgrt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
+                      const float* materials, uint32_t nmesh, const float* spheres, uint32_t nspheres, int device, CgrtScene** out) {
+    if (!out) return fail(CGRT_E_ARG, "out is NULL");
+    *out = nullptr;
+    if ((nverts && !pos_nrm) || (ntris && (!tri || !tri_mesh)) || (nmesh && !materials) || (nspheres && !spheres))
+        return fail(CGRT_E_ARG, "NULL array with non-zero count");
+    if (ntris && (!nverts || !nmesh)) return fail(CGRT_E_ARG, "triangles without vertices or meshes");
+    // device == CGRT_DEVICE_NONE builds the tree on the host only (introspection, builder tests);
+    // every trace/intersect entry then fails with CGRT_E_NO_DEVICE -- there is no CPU traversal.
+    int rc = (device == CGRT_DEVICE_NONE) ? CGRT_OK : select_device(device);
+    if (rc) return rc;
+
+    HostScene hs;
+    hs.nverts = nverts;
+    hs.ntris = ntris;
+    hs.nmesh = nmesh;
+    hs.nspheres = nspheres;
+    try {
+        hs.pos_nrm.assign(pos_nrm, pos_nrm + 6 * (size_t)nverts);
+        hs.tri.assign(tri, tri + 3 * (size_t)ntris);
+        hs.tri_mesh.assign(tri_mesh, tri_mesh + ntris);
+        hs.materials.assign(materials, materials + 8 * (size_t)nmesh);
+        if (nspheres) hs.spheres.assign(spheres, spheres + 5 * (size_t)nspheres);
+        CgrtScene* s = new CgrtScene();
+        s->device = device;
+        s->ntris = ntris;
+        std::string err;
+        if (!build_reference_bvh(hs, s->bvh, err)) {
+            delete s;
+            return fail(err.find("deeper") != std::string::npos ? CGRT_E_LIMIT : CGRT_E_ARG, err);
+        }
+        if (device == CGRT_DEVICE_NONE) {
+            *out = s;
+            return CGRT_OK;
+        }
+        uint64_t total = 0;
+        if ((rc = upload(s->bvh.packets, &s->d_packets, total)) || (rc = upload(s->bvh.leaves, &s->d_leaves, total)) ||
+            (rc = upload(s->bvh.tris, &s->d_tris, total)) || (rc = upload(s->bvh.tri_normals, &s->d_tri_normals, total)) ||
+            (rc = upload(s->bvh.spheres, &s->d_spheres, total))) {
+            delete s;
+            return rc;
+        }
+        hipError_t e = hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long));
+        if (e != hipSuccess) {
+            delete s;
+            return hip_fail(e, "hipMalloc(counters)");
+        }
+        s->device_bytes = total;
+        SceneDev& D = s->dev;
+        D.packets = static_cast<const NodePacket*>(s->d_packets);
+        D.leaves = static_cast<const LeafRec*>(s->d_leaves);
+        D.tris = static_cast<const TriRecord*>(s->d_tris);
+        D.tri_normals = static_cast<const TriNormals*>(s->d_tri_normals);
+        D.spheres = static_cast<const SphereRecord*>(s->d_spheres);
+        D.root_box = s->bvh.root_box;
+        D.root_ref = s->bvh.root_ref;
+        D.ntris = ntris;
+        D.nspheres = nspheres;
+        D.npackets = (uint32_t)s->bvh.packets.size();
+        D.nleaves = (uint32_t)s->bvh.leaves.size();
+        *out = s;
+    } catch (const std::bad_alloc&) {
+        return fail(CGRT_E_ALLOC, "host allocation failed");
+    }
+    return CGRT_OK;
+}
+
+void cgrt_scene_destroy(CgrtScene* scene) { delete scene; }
+
+int cgrt_num_levels(const CgrtScene* s) { return s ? s->bvh.levels : fail(CGRT_E_ARG, "scene is NULL"); }
+int cgrt_num_nodes(const CgrtScene* s) { return s ? (int)s->bvh.nodes.size() : fail(CGRT_E_ARG, "scene is NULL"); }
+double cgrt_build_seconds(const CgrtScene* s) { return s ? s->bvh.build_seconds : 0.0; }
+uint64_t cgrt_device_bytes(const CgrtScene* s) { return s ? s->device_bytes : 0; }
+
+int cgrt_get_nodes(const CgrtScene* s, int32_t* meta, float* boxes) {
+    if (!s || !meta || !boxes) return fail(CGRT_E_ARG, "NULL argument");
+    for (size_t i = 0; i < s->bvh.nodes.size(); i++) {
+        const TopoNode& n = s->bvh.nodes[i];
+        meta[5 * i] = n.leaf;
+        meta[5 * i + 1] = n.level;
+        meta[5 * i + 2] = n.child[0];
+        meta[5 * i + 3] = n.child[1];
+        meta[5 * i + 4] = (int32_t)n.count;
+        std::memcpy(boxes + 6 * i, &n.box, 24);
+    }
+    return CGRT_OK;
+}
+
+int64_t cgrt_leaf_prims(const CgrtScene* s, int node, uint32_t* out, uint32_t cap) {
+    if (!s || node < 0 || (size_t)node >= s->bvh.nodes.size()) return fail(CGRT_E_ARG, "bad node");
+    const TopoNode& n = s->bvh.nodes[node];
+    for (uint32_t k = 0; k < n.count && k < cap; k++) out[k] = s->bvh.order[n.first + k];
+    return n.count;
+}
+
+void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes) {
+    if (node_bytes) *node_bytes = sizeof(NodePacket);
+    if (tri_bytes) *tri_bytes = sizeof(TriRecord);
+    if (sub_bytes) *sub_bytes = 0;
+    if (hit_bytes) *hit_bytes = sizeof(CgrtHit);
+}
+
+// ------------------------------------------------------------------------------------------------
+#define NEED_DEVICE(s) \
+    if ((s)->device < 0) return fail(CGRT_E_NO_DEVICE, "scene was created host-only (CGRT_DEVICE_NONE); there is no CPU traversal path")
+
+int cgrt_intersect_batch_device(CgrtScene* s, const CgrtRay* d_rays, uint64_t n, CgrtHit* d_hits, float* d_normals, void* stream) {
+    if (!s || (n && (!d_rays || !d_hits))) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_trace_batch(s->dev, reinterpret_cast<const float*>(d_rays), n, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals,
+                               nullptr, static_cast<hipStream_t>(stream)));
+    return CGRT_OK;
+}
+
+int cgrt_intersect_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtHit* hits, float* normals) {
+    if (!s || (n && (!rays || !hits))) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    if (n == 0) return CGRT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dr, dh, dn;
+    HIP_TRY(dr.alloc(n * sizeof(CgrtRay)));
+    HIP_TRY(dh.alloc(n * sizeof(CgrtHit)));
+    HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(CgrtRay), hipMemcpyHostToDevice));
+    if (normals) {
+        HIP_TRY(dn.alloc(n * 12));
+        // HitInfo is left untouched on a miss: start from the caller's contents
+        HIP_TRY(hipMemcpy(dn.p, normals, n * 12, hipMemcpyHostToDevice));
+    }
+    int rc = cgrt_intersect_batch_device(s, dr.as<CgrtRay>(), n, dh.as<CgrtHit>(), normals ? dn.as<float>() : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(CgrtHit), hipMemcpyDeviceToHost));
+    if (normals) HIP_TRY(hipMemcpy(normals, dn.p, n * 12, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_trace_primary_device(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1, int rank, int nranks,
+                              CgrtHit* d_hits, float* d_normals, void* stream) {
+    if (!s || !cam || !d_hits) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    FrameDev F;
+    if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr,
+                                 static_cast<hipStream_t>(stream)));
+    return CGRT_OK;
+}
+
+int cgrt_trace_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1, int rank, int nranks,
+                       CgrtHit* hits, float* normals) {
+    if (!s || !cam || !hits) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    if (W <= 0 || H <= 0) return fail(CGRT_E_ARG, "bad frame size");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npix = (size_t)W * (size_t)H;
+    DevBuf dh, dn;
+    HIP_TRY(dh.alloc(npix * sizeof(CgrtHit)));
+    HIP_TRY(hipMemcpy(dh.p, hits, npix * sizeof(CgrtHit), hipMemcpyHostToDevice));  // pixels outside the tiles keep caller data
+    if (normals) {
+        HIP_TRY(dn.alloc(npix * 12));
+        HIP_TRY(hipMemcpy(dn.p, normals, npix * 12, hipMemcpyHostToDevice));
+    }
+    int rc = cgrt_trace_primary_device(s, cam, W, H, x0, y0, x1, y1, rank, nranks, dh.as<CgrtHit>(), normals ? dn.as<float>() : nullptr,
+                                       nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hits, dh.p, npix * sizeof(CgrtHit), hipMemcpyDeviceToHost));
+    if (normals) HIP_TRY(hipMemcpy(normals, dn.p, npix * 12, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_generate_rays(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1, CgrtRay* rays) {
+    if (!s || !cam || !rays) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    FrameDev F;
+    if (!make_frame(W, H, x0, y0, x1, y1, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame rectangle");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = (size_t)(x1 - x0) * (size_t)(y1 - y0);
+    if (!n) return CGRT_OK;
+    DevBuf dr;
+    HIP_TRY(dr.alloc(n * sizeof(CgrtRay)));
+    HIP_TRY(launch_generate_rays(make_camera(*cam), W, H, x0, y0, x1, y1, dr.as<float>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rays, dr.p, n * sizeof(CgrtRay), hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+static int read_counters(CgrtScene* s, CgrtCounters* out) {
+    unsigned long long h[5];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out->rays = h[0];
+    out->inner_visits = h[1];
+    out->leaf_visits = h[2];
+    out->tri_tests = h[3];
+    out->sub_visits = h[4];
+    return CGRT_OK;
+}
+
+int cgrt_count_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1, int rank, int nranks,
+                       CgrtCounters* out) {
+    if (!s || !cam || !out) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    FrameDev F;
+    if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dh;
+    HIP_TRY(dh.alloc((size_t)W * (size_t)H * sizeof(CgrtHit)));
+    HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, dh.as<CgrtHitDev>(), nullptr, s->d_counters, nullptr));
+    return read_counters(s, out);
+}
+
+int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters* out) {
+    if (!s || !out || (n && !rays)) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dr, dh;
+    HIP_TRY(dr.alloc(n * sizeof(CgrtRay)));
+    HIP_TRY(dh.alloc(n * sizeof(CgrtHit)));
+    if (n) HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(CgrtRay), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(launch_trace_batch(s->dev, dr.as<float>(), n, dh.as<CgrtHitDev>(), nullptr, s->d_counters, nullptr));
+    return read_counters(s, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise primitives
+#define PRIM_PROLOGUE(device)           \
+    int rc_ = select_device(device);    \
+    if (rc_) return rc_;                \
+    if (n == 0) return CGRT_OK;
+
+int cgrt_ray_triangle_batch(int device, const float* tri, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit, float* normals) {
+    if (n && (!tri || !rays || !t_out || !hit)) return fail(CGRT_E_ARG, "NULL argument");
+    PRIM_PROLOGUE(device)
+    DevBuf a, r, t, h, nn;
+    HIP_TRY(a.alloc(n * 72));
+    HIP_TRY(r.alloc(n * 28));
+    HIP_TRY(t.alloc(n * 4));
+    HIP_TRY(h.alloc(n));
+    HIP_TRY(hipMemcpy(a.p, tri, n * 72, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r.p, rays, n * 28, hipMemcpyHostToDevice));
+    if (normals) {
+        HIP_TRY(nn.alloc(n * 12));
+        HIP_TRY(hipMemcpy(nn.p, normals, n * 12, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(launch_ray_triangle(a.as<float>(), r.as<float>(), n, t.as<float>(), h.as<uint8_t>(), normals ? nn.as<float>() : nullptr, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(t_out, t.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hit, h.p, n, hipMemcpyDeviceToHost));
+    if (normals) HIP_TRY(hipMemcpy(normals, nn.p, n * 12, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_ray_plane_batch(int device, const float* plane, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit) {
+    if (n && (!plane || !rays || !t_out || !hit)) return fail(CGRT_E_ARG, "NULL argument");
+    PRIM_PROLOGUE(device)
+    DevBuf a, r, t, h;
+    HIP_TRY(a.alloc(n * 16));
+    HIP_TRY(r.alloc(n * 28));
+    HIP_TRY(t.alloc(n * 4));
+    HIP_TRY(h.alloc(n));
+    HIP_TRY(hipMemcpy(a.p, plane, n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r.p, rays, n * 28, hipMemcpyHostToDevice));
+    HIP_TRY(launch_ray_plane(a.as<float>(), r.as<float>(), n, t.as<float>(), h.as<uint8_t>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(t_out, t.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hit, h.p, n, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_ray_box_batch(int device, const float* box, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit, uint8_t* inside) {
+    if (n && (!box || !rays || !t_out || !hit)) return fail(CGRT_E_ARG, "NULL argument");
+    PRIM_PROLOGUE(device)
+    DevBuf a, r, t, h, in;
+    HIP_TRY(a.alloc(n * 24));
+    HIP_TRY(r.alloc(n * 28));
+    HIP_TRY(t.alloc(n * 4));
+    HIP_TRY(h.alloc(n));
+    HIP_TRY(in.alloc(n));
+    HIP_TRY(hipMemcpy(a.p, box, n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r.p, rays, n * 28, hipMemcpyHostToDevice));
+    HIP_TRY(launch_ray_box(a.as<float>(), r.as<float>(), n, t.as<float>(), h.as<uint8_t>(), in.as<uint8_t>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(t_out, t.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hit, h.p, n, hipMemcpyDeviceToHost));
+    if (inside) HIP_TRY(hipMemcpy(inside, in.p, n, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_ray_sphere_batch(int device, const float* sphere, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit, float* normals) {
+    if (n && (!sphere || !rays || !t_out || !hit)) return fail(CGRT_E_ARG, "NULL argument");
+    PRIM_PROLOGUE(device)
+    DevBuf a, r, t, h, nn;
+    HIP_TRY(a.alloc(n * 16));
+    HIP_TRY(r.alloc(n * 28));
+    HIP_TRY(t.alloc(n * 4));
+    HIP_TRY(h.alloc(n));
+    HIP_TRY(hipMemcpy(a.p, sphere, n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r.p, rays, n * 28, hipMemcpyHostToDevice));
+    if (normals) {
+        HIP_TRY(nn.alloc(n * 12));
+        HIP_TRY(hipMemcpy(nn.p, normals, n * 12, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(launch_ray_sphere(a.as<float>(), r.as<float>(), n, t.as<float>(), h.as<uint8_t>(), normals ? nn.as<float>() : nullptr, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(t_out, t.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hit, h.p, n, hipMemcpyDeviceToHost));
+    if (normals) HIP_TRY(hipMemcpy(normals, nn.p, n * 12, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_triangle_plane_batch(int device, const float* tri, uint64_t n, float* plane) {
+    if (n && (!tri || !plane)) return fail(CGRT_E_ARG, "NULL argument");
+    PRIM_PROLOGUE(device)
+    DevBuf a, p;
+    HIP_TRY(a.alloc(n * 36));
+    HIP_TRY(p.alloc(n * 16));
+    HIP_TRY(hipMemcpy(a.p, tri, n * 36, hipMemcpyHostToDevice));
+    HIP_TRY(launch_triangle_plane(a.as<float>(), n, p.as<float>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(plane, p.p, n * 16, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_point_in_triangle_batch(int device, const float* in, uint64_t n, uint8_t* out) {
+    if (n && (!in || !out)) return fail(CGRT_E_ARG, "NULL argument");
+    PRIM_PROLOGUE(device)
+    DevBuf a, o;
+    HIP_TRY(a.alloc(n * 60));
+    HIP_TRY(o.alloc(n));
+    HIP_TRY(hipMemcpy(a.p, in, n * 60, hipMemcpyHostToDevice));
+    HIP_TRY(launch_point_in_triangle(a.as<float>(), n, o.as<uint8_t>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, o.p, n, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// cgrt_layout.h -- records shared by the host builder and the gfx950 kernels (HBM layout).
+#pragma once
+#include <stdint.h>
+
+namespace cgrt {
+
+// Child reference of a reference-topology node: bit 31 set -> leaf, low bits = index into the leaf
+// table; clear -> index of the inner node's NodePacket.
+static const uint32_t REF_LEAF = 0x80000000u;
+static const uint32_t REF_NONE = 0xffffffffu;
+static const int MAX_LEVELS = 12;  // bvh.cpp:48 maxDepth; per-ray stack never exceeds MAX_LEVELS - 1
+
+// One inner node of the reference tree with BOTH child boxes (64 B, one cache-line half): the two
+// slab tests + two startsInBox tests of intersectNonLeaf/intersectDeeper (bvh.cpp:715-736, :679-701)
+// need exactly this and nothing else.
+struct alignas(16) NodePacket {
+    float lbox[6];  // left child AABB lower.xyz, upper.xyz
+    float rbox[6];  // right child AABB
+    uint32_t left;  // child refs
+    uint32_t right;
+    uint32_t pad[2];
+};
+static_assert(sizeof(NodePacket) == 64, "NodePacket must be 64 B");
+
+// One reference leaf: a run of TriRecords in intersectLeaf scan order (bvh.cpp:538-551) and, when the
+// in-leaf accelerator is built, the root of its sub-tree.
+struct LeafRec {
+    uint32_t first;  // first TriRecord
+    uint32_t count;
+    uint32_t sub_root;  // index of the leaf's first SubNode, REF_NONE when the leaf is scanned linearly
+    uint32_t pad;
+};
+static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
+
+// One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent
+// trianglePlane (ray_tracing.cpp:74-82) evaluated once on the host with the reference's arithmetic.
+struct alignas(16) TriRecord {
+    float v0[3];
+    float v1[3];
+    float v2[3];
+    float n[3];
+    float D;
+    uint32_t prim_id;  // global triangle index
+    uint32_t mesh_id;  // -> hitInfo.material
+    uint32_t pad;
+};
+static_assert(sizeof(TriRecord) == 64, "TriRecord must be 64 B");
+
+// Vertex normals of a triangle, read once per ray for the accepted hit (ray_tracing.cpp:94-98).
+struct TriNormals {
+    float n1[3], n2[3], n3[3];
+};
+static_assert(sizeof(TriNormals) == 36, "TriNormals must be 36 B");
+
+struct SphereRecord {
+    float c[3];
+    float radius;
+};
+
+struct Box6 {
+    float lo[3], hi[3];
+};
+
+// Everything a kernel needs, passed by value.
+struct SceneDev {
+    const NodePacket* packets;
+    const LeafRec* leaves;
+    const TriRecord* tris;
+    const TriNormals* tri_normals;  // indexed like tris (leaf order)
+    const SphereRecord* spheres;
+    Box6 root_box;
+    uint32_t root_ref;  // REF_NONE when the scene has no meshes (bvh.cpp:870)
+    uint32_t ntris;
+    uint32_t nspheres;
+    uint32_t npackets;
+    uint32_t nleaves;
+};
+
+// Camera constants evaluated once on the host (trackball.cpp:70-73, :92-103): position, quaternion,
+// half extents of the image plane.  The per-pixel part runs on the device.
+struct CameraDev {
+    float pos[3];
+    float q[4];  // w x y z
+    float half_w, half_h;
+};
+
+struct FrameDev {
+    int W, H;
+    int x0, y0, x1, y1;
+    int tiles_x, tiles_y;  // 8x8 tiles covering the rectangle
+    int rank, nranks;
+    uint32_t ntiles_rank;  // tiles this rank owns
+};
+
+}  // namespace cgrt

@@ -1,0 +1,35 @@
+// trace_kernels.h -- host-callable launchers of the gfx950 kernels in trace_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cgrt_layout.h"
+
+namespace cgrt {
+
+// Device mirror of CgrtHit (include/cgrt.h), 16 B.
+struct CgrtHitDev {
+    float t;
+    uint32_t prim_id;
+    int32_t material_id;
+    uint32_t hit;
+};
+
+// counters (optional): 5 x u64 device words {rays, inner_visits, leaf_visits, tri_tests, sub_visits}, accumulated.
+hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
+                                unsigned long long* counters, hipStream_t stream);
+hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
+                              unsigned long long* counters, hipStream_t stream);
+hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);
+
+hipError_t launch_ray_triangle(const float* tri, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, float* normals,
+                               hipStream_t s);
+hipError_t launch_ray_plane(const float* plane, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, hipStream_t s);
+hipError_t launch_ray_box(const float* box, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, uint8_t* inside,
+                          hipStream_t s);
+hipError_t launch_ray_sphere(const float* sph, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, float* normals,
+                             hipStream_t s);
+hipError_t launch_triangle_plane(const float* tri, unsigned long long n, float* plane, hipStream_t s);
+hipError_t launch_point_in_triangle(const float* in, unsigned long long n, uint8_t* out, hipStream_t s);
+
+}  // namespace cgrt

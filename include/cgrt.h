@@ -1,0 +1,156 @@
+/* cgrt.h -- C-ABI of the MI355X-native BVH traversal + ray/triangle path.
+ *
+ * The reference (mgokbulut/CG-RayTracer) has no FFI / plugin layer: its hot path is the C++ class
+ * BoundingVolumeHierarchy (src/bounding_volume_hierarchy.h:15-56) plus the free functions of
+ * src/ray_tracing.h:10-20, called one ray at a time from src/main.cpp:115,182,276.  This header is
+ * the boundary a maintainer would bind instead; every entry names the reference
+ * interface it replaces.  Plain C types only, caller-allocated outputs, no exceptions cross it.
+ *
+ * Every function that returns int returns 0 on success and a negative CGRT_E_* code on failure;
+ * cgrt_last_error() then describes the failure (thread-local string).  There is NO CPU fallback:
+ * without a usable HIP device cgrt_scene_create fails with CGRT_E_NO_DEVICE.
+ */
+#ifndef CGRT_H
+#define CGRT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGRT_OK 0
+#define CGRT_E_ARG (-1)       /* bad argument (null pointer, inconsistent counts, index out of range) */
+#define CGRT_E_NO_DEVICE (-2) /* no HIP device / device index out of range */
+#define CGRT_E_HIP (-3)       /* a HIP runtime call failed */
+#define CGRT_E_ALLOC (-4)     /* host or device allocation failed */
+#define CGRT_E_LIMIT (-5)     /* scene exceeds a structural limit (BVH deeper than 12 levels) */
+
+#define CGRT_NO_PRIM 0xffffffffu
+#define CGRT_DEVICE_NONE (-1) /* cgrt_scene_create: build on the host only, no device upload */
+
+/* Ray: bit-compatible with the reference's `Ray` (framework/include/ray.h:9-13): 28 bytes. */
+typedef struct CgrtRay {
+    float origin[3];
+    float direction[3];
+    float t; /* in: current closest t (FLT_MAX for a fresh ray) */
+} CgrtRay;
+
+/* Result of BoundingVolumeHierarchy::intersect for one ray (bounding_volume_hierarchy.cpp:850-881).
+ *   t           final ray.t (unchanged input t on a miss)
+ *   prim_id     last accepted primitive: global triangle index (prefix over Scene::meshes in load
+ *               order + index in Mesh::triangles), or ntris + sphere index; CGRT_NO_PRIM on a miss.
+ *               The reference has no primitive id (HitInfo = normal + material, ray_tracing.h:4-8);
+ *               this is the definition of SURVEY.md section 8(c).
+ *   material_id index of the mesh whose Material the reference copies into hitInfo.material
+ *               (bvh.cpp:547), -1 if never written (miss, or sphere-only hit: bvh.cpp:878-879).
+ *   hit         the bool the reference returns. */
+typedef struct CgrtHit {
+    float t;
+    uint32_t prim_id;
+    int32_t material_id;
+    uint32_t hit;
+} CgrtHit;
+
+/* Trackball camera state (framework/include/trackball.h:48-56; defaults src/main.cpp:730-731). */
+typedef struct CgrtCamera {
+    float look_at[3];
+    float euler[3]; /* radians */
+    float distance;
+    float fovy;   /* radians, vertical */
+    float aspect; /* Window::aspectRatio(), framework/src/window.cpp:334-337 */
+} CgrtCamera;
+
+/* Totals of the traversal work for a batch (SURVEY.md section 8(d) algorithmic-bytes definition). */
+typedef struct CgrtCounters {
+    uint64_t rays;
+    uint64_t inner_visits; /* reference inner nodes visited (intersectNonLeaf calls, bvh.cpp:715) */
+    uint64_t leaf_visits;  /* reference leaves visited (intersectLeaf calls, bvh.cpp:535) */
+    uint64_t tri_tests;    /* triangle records tested on the device */
+    uint64_t sub_visits;   /* in-leaf accelerator nodes visited (0 when leaves are scanned linearly) */
+} CgrtCounters;
+
+typedef struct CgrtScene CgrtScene;
+
+/* Replaces BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene*) (bvh.cpp:42-76): builds the
+ * reference's 12-level median-split tree on the host (same topology, same leaf order), flattens it
+ * and uploads it to `device`.  With device == CGRT_DEVICE_NONE nothing is uploaded: the tree can be
+ * inspected (cgrt_num_levels, cgrt_get_nodes, cgrt_leaf_prims) but every trace/intersect entry fails with
+ * CGRT_E_NO_DEVICE.
+ *   pos_nrm   nverts x 6 floats (Vertex{p, n}, mesh.h:12-15), all meshes concatenated
+ *   tri       ntris x 3 indices into pos_nrm, meshes concatenated in load order
+ *   tri_mesh  ntris mesh indices, non-decreasing
+ *   materials nmesh x 8 floats (Material{kd, ks, shininess, transparency}, mesh.h:17-23)
+ *   spheres   nspheres x 5 floats {center, radius, material index or -1} (scene.h:36-40), may be NULL */
+int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh,
+                      uint32_t ntris, const float* materials, uint32_t nmesh, const float* spheres,
+                      uint32_t nspheres, int device, CgrtScene** out);
+void cgrt_scene_destroy(CgrtScene* scene);
+
+/* BoundingVolumeHierarchy::numLevels() (bvh.cpp:214-224). */
+int cgrt_num_levels(const CgrtScene* scene);
+/* Tree introspection for builder-parity tests (the reference keeps std::vector<Node>, bvh.h:6-13).
+ * meta: nnodes x 5 int32 {is_leaf, level, child0, child1, ntris}; boxes: nnodes x 6 floats. */
+int cgrt_num_nodes(const CgrtScene* scene);
+int cgrt_get_nodes(const CgrtScene* scene, int32_t* meta, float* boxes);
+/* prim ids of leaf `node` in the order intersectLeaf scans them (bvh.cpp:538-551). Returns count. */
+int64_t cgrt_leaf_prims(const CgrtScene* scene, int node, uint32_t* out, uint32_t cap);
+double cgrt_build_seconds(const CgrtScene* scene);
+uint64_t cgrt_device_bytes(const CgrtScene* scene);
+
+/* Batched BoundingVolumeHierarchy::intersect(Ray&, HitInfo&) (bvh.cpp:850-881): n independent rays.
+ * normals (optional, n x 3) receives hitInfo.normal for rays that hit (left untouched otherwise, as
+ * the reference leaves HitInfo untouched on a miss).  Host pointers; synchronous. */
+int cgrt_intersect_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, CgrtHit* hits, float* normals);
+/* Same, all pointers are DEVICE pointers on the scene's device; asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream). */
+int cgrt_intersect_batch_device(CgrtScene* scene, const CgrtRay* d_rays, uint64_t n, CgrtHit* d_hits,
+                                float* d_normals, void* stream);
+
+/* Primary frame: fuses renderRayTracing's ray generation (main.cpp:691-694 + Trackball::generateRay,
+ * trackball.cpp:92-103) with intersect; no rays are uploaded.  Pixel (x, y), 0 <= x < W, 0 <= y < H,
+ * result index y*W + x (not y-flipped).  Only pixels inside [x0,x1) x [y0,y1) whose 8x8 tile satisfies
+ * tile_index % nranks == rank are traced and written (image tiling across GPUs). */
+int cgrt_trace_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,
+                       int rank, int nranks, CgrtHit* hits, float* normals);
+int cgrt_trace_primary_device(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1,
+                              int y1, int rank, int nranks, CgrtHit* d_hits, float* d_normals, void* stream);
+/* The rays the fused kernel generates, written out for "same rays" parity checks (row-major over the
+ * rectangle). Host pointer. */
+int cgrt_generate_rays(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,
+                       CgrtRay* rays);
+
+/* Work counters of the same traversal (separate instrumented launch; not part of any timed region). */
+int cgrt_count_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,
+                       int rank, int nranks, CgrtCounters* out);
+int cgrt_count_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, CgrtCounters* out);
+/* Bytes of one inner-node record / one triangle record / one in-leaf accelerator node / one result. */
+void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes);
+
+/* Element-wise device versions of the free functions of src/ray_tracing.h:10-20 and startsInBox
+ * (bvh.cpp:647-661); element i of every array belongs to call i.  Host pointers; synchronous.
+ *   cgrt_ray_triangle_batch  intersectRayWithTriangle (ray_tracing.cpp:86-114)
+ *       tri: n x 18 floats {v0 v1 v2 n1 n2 n3}; t_io: n floats in/out; hit: n bytes; normals n x 3 (written on hit)
+ *   cgrt_ray_plane_batch     intersectRayWithPlane (ray_tracing.cpp:40-72); plane: n x 4 {D, normal}
+ *   cgrt_ray_box_batch       intersectRayWithShape(AxisAlignedBox) (ray_tracing.cpp:162-200) and startsInBox;
+ *       box: n x 6 {lower, upper}; inside: n bytes (optional)
+ *   cgrt_ray_sphere_batch    intersectRayWithShape(Sphere) (ray_tracing.cpp:118-158); sphere: n x 4 {center, radius}
+ *   cgrt_triangle_plane_batch trianglePlane (ray_tracing.cpp:74-82); tri: n x 9 -> plane n x 4 {D, normal}
+ *   cgrt_point_in_triangle_batch pointInTriangle (ray_tracing.cpp:23-38); in: n x 15 {v0 v1 v2 n p} */
+int cgrt_ray_triangle_batch(int device, const float* tri, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit,
+                            float* normals);
+int cgrt_ray_plane_batch(int device, const float* plane, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit);
+int cgrt_ray_box_batch(int device, const float* box, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit,
+                       uint8_t* inside);
+int cgrt_ray_sphere_batch(int device, const float* sphere, const CgrtRay* rays, uint64_t n, float* t_out, uint8_t* hit,
+                          float* normals);
+int cgrt_triangle_plane_batch(int device, const float* tri, uint64_t n, float* plane);
+int cgrt_point_in_triangle_batch(int device, const float* in, uint64_t n, uint8_t* out);
+
+int cgrt_device_count(void);
+const char* cgrt_last_error(void);
+const char* cgrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGRT_H */

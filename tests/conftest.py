@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as entry  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    p = entry.load_package()
+    if not os.path.exists(p.LIB_PATH):
+        p.build_native()
+    return p
+
+
+@pytest.fixture(scope="session")
+def orc():
+    o = entry.load_oracle()
+    if not os.path.exists(o.LIB):
+        o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def scene_data(pkg):
+    """name -> SceneData from the committed fixtures (tests/golden/scenes/*.npz)."""
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            if name == "blob":
+                cache[name] = pkg.scenes.make_blob(2000, seed=7)
+            elif name == "spheres":
+                cache[name] = pkg.scenes.spheres_preset()
+            else:
+                cache[name] = pkg.scenes.SceneData.load(os.path.join(GOLDEN, "scenes", name + ".npz"))
+                cache[name].name = name
+        return cache[name]
+
+    return get
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)

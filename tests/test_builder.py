@@ -1,0 +1,63 @@
+"""Host logic, no GPU: the product's flat BVH builder (cg-raytracer_amd/csrc/bvh_builder.cpp, through the
+C-ABI with CGRT_DEVICE_NONE) must produce the reference topology, boxes and leaf order of the oracle's
+restatement of bounding_volume_hierarchy.cpp:42-372, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+
+def _same_tree(o, s):
+    m1, b1 = o.nodes()
+    m2, b2 = s.nodes()
+    assert np.array_equal(m1, m2)
+    assert np.array_equal(bits(b1), bits(b2))
+    for i in np.nonzero(m1[:, 0] == 1)[0]:
+        assert np.array_equal(o.leaf_prims(int(i)), s.leaf_prims(int(i))), f"leaf {i} order differs"
+    assert o.num_levels() == s.num_levels()
+
+
+@pytest.mark.parametrize("name", ["triangle", "cube", "cornell", "monkey", "dodge", "blob"])
+def test_tree_matches_oracle(pkg, orc, scene_data, name):
+    sd = scene_data(name)
+    _same_tree(orc.OracleScene(sd), pkg.Scene(sd, device=-1))
+
+
+def test_tree_matches_oracle_dragon_60k(pkg, orc):
+    sd = pkg.scenes.make_dragon(60_000)
+    o, s = orc.OracleScene(sd), pkg.Scene(sd, device=-1)
+    _same_tree(o, s)
+    assert s.num_levels() == 12
+    meta, _ = s.nodes()
+    leaves = meta[meta[:, 0] == 1]
+    assert leaves[:, 4].sum() == sd.ntris and len(leaves) == 2048
+
+
+def test_equal_keys_keep_std_sort_order(pkg, orc):
+    """Many equal centroid keys: leaf order then depends on libstdc++'s introsort."""
+    rng = np.random.RandomState(3)
+    n = 700
+    # triangles on a coarse lattice => massive key ties on every axis
+    base = rng.randint(0, 4, (n, 3)).astype(np.float32)
+    tri = np.stack([base, base + [1, 0, 0], base + [0, 1, 0]], 1).reshape(-1, 3).astype(np.float32)
+    pn = np.concatenate([tri, np.tile(np.float32([[0, 0, 1]]), (3 * n, 1))], 1)
+    sd = pkg.scenes.SceneData(pos_nrm=pn, tri=np.arange(3 * n, dtype=np.uint32).reshape(n, 3), tri_mesh=np.zeros(n, np.uint32),
+                              materials=np.ones((1, 8), np.float32))
+    _same_tree(orc.OracleScene(sd), pkg.Scene(sd, device=-1))
+
+
+def test_multi_mesh_split_and_empty_mesh(pkg, orc, scene_data):
+    sd = scene_data("cornell")
+    # insert an empty mesh id in the middle: ids 0..3, (4 empty), 5..8
+    tm = sd.tri_mesh.copy()
+    tm[tm >= 4] += 1
+    mats = np.insert(sd.materials, 4, np.zeros(8, np.float32), axis=0)
+    sd2 = pkg.scenes.SceneData(pos_nrm=sd.pos_nrm, tri=sd.tri, tri_mesh=tm, materials=mats)
+    _same_tree(orc.OracleScene(sd2), pkg.Scene(sd2, device=-1))
+
+
+def test_empty_scene(pkg, orc):
+    sd = pkg.scenes.spheres_preset()
+    s = pkg.Scene(sd, device=-1)
+    assert s.num_levels() == 1 == orc.OracleScene(sd).num_levels()  # numLevels() of no nodes (bvh.cpp:214-224)
+    assert s.nodes()[0].shape == (0, 5)

@@ -1,0 +1,299 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs and against the committed golden fixtures.  Bar: bit-exact hit flag, t (u32 pattern),
+primitive id, material id; hitInfo.normal bit-exact too (it is computed with the reference's double-precision
+area formula on both sides)."""
+import os
+
+import numpy as np
+import pytest
+
+import rayfam
+from conftest import GOLDEN, bits
+
+pytestmark = pytest.mark.gpu
+FMAX = rayfam.FMAX
+
+
+def _rays(pkg, r7):
+    return np.ascontiguousarray(r7, np.float32).view(pkg.RAY_DTYPE).reshape(-1)
+
+
+def _assert_hits_equal(hits, normals, ref, what=""):
+    assert np.array_equal(hits["hit"], ref["hit"]), f"{what}: hit flags differ on {(hits['hit'] != ref['hit']).sum()} rays"
+    bad = bits(hits["t"]) != bits(ref["t"])
+    assert not bad.any(), f"{what}: t bits differ on {bad.sum()} rays, first {np.nonzero(bad)[0][:5]}"
+    assert np.array_equal(hits["prim_id"], ref["prim"]), f"{what}: primitive ids differ"
+    assert np.array_equal(hits["material_id"], ref["material"]), f"{what}: material ids differ"
+    if normals is not None:
+        m = ref["hit"] == 1
+        assert np.array_equal(bits(normals[m]), bits(ref["normal"][m])), f"{what}: normals differ"
+
+
+# ---------------------------------------------------------------------------------------------------
+# primitives (src/ray_tracing.h:10-20)
+# ---------------------------------------------------------------------------------------------------
+def _random_rays(rng, n, scale=1.0):
+    r = np.zeros((n, 7), np.float32)
+    r[:, 0:3] = rng.uniform(-2, 2, (n, 3)) * scale
+    d = rng.normal(size=(n, 3))
+    r[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    r[:, 6] = FMAX
+    return r
+
+
+def test_ray_triangle_primitive(pkg, orc):
+    rng = np.random.RandomState(11)
+    n = 200_000
+    tri = rng.uniform(-1, 1, (n, 18)).astype(np.float32)
+    r = _random_rays(rng, n)
+    # aim most rays at a point of their triangle so that hits are common
+    w = rng.dirichlet((1, 1, 1), n).astype(np.float32)
+    tgt = w[:, 0:1] * tri[:, 0:3] + w[:, 1:2] * tri[:, 3:6] + w[:, 2:3] * tri[:, 6:9]
+    d = tgt - r[:, 0:3]
+    r[: n // 2, 3:6] = (d / np.linalg.norm(d, axis=1, keepdims=True))[: n // 2]
+    r[::7, 6] = rng.uniform(0, 3, len(r[::7]))  # finite t
+    # exact on-plane origins on axis-aligned triangles, scaled directions, denormal-ish geometry
+    tri[:1000, [2, 5, 8]] = 0.5
+    r[:1000, 2] = 0.5
+    tri[1000:2000] *= np.float32(1e-18)
+    r[1000:2000, 0:3] *= np.float32(1e-18)
+    r[2000:3000, 3:6] *= np.float32(1e-20)
+    r[3000:4000, 3:6] *= np.float32(1e15)
+    t, hit, nrm = pkg.ray_triangle(tri, _rays(pkg, r))
+    ref = orc.ray_triangle(tri, r)
+    assert 0.2 < hit.mean() < 0.8
+    assert np.array_equal(hit, ref["hit"].astype(np.uint8))
+    assert np.array_equal(bits(t), bits(ref["t"]))
+    m = hit == 1
+    assert np.array_equal(bits(nrm[m]), bits(ref["normal"][m]))
+
+
+def test_ray_plane_and_triangle_plane_and_point_in_triangle(pkg, orc):
+    rng = np.random.RandomState(12)
+    n = 100_000
+    tri9 = rng.uniform(-1, 1, (n, 9)).astype(np.float32)
+    tri9[:500] *= np.float32(1e-15)  # tiny triangles: normalisation of tiny cross products
+    tri9[500:600, 3:6] = tri9[500:600, 0:3]  # degenerate: NaN normal
+    pl = pkg.triangle_plane(tri9)
+    assert np.array_equal(bits(pl), bits(orc.triangle_plane(tri9)))
+    r = _random_rays(rng, n)
+    r[::5, 6] = rng.uniform(0, 3, len(r[::5]))
+    r[:2000, 3:6] = 0.0  # zero direction
+    pl2 = pl.copy()
+    pl2[5000:6000, 0] = (r[5000:6000, 0:3] * pl2[5000:6000, 1:4]).astype(np.float32).sum(1)  # near on-plane
+    t, hit = pkg.ray_plane(pl2, _rays(pkg, r))
+    ref = orc.ray_plane(pl2, r)
+    assert np.array_equal(hit, ref["hit"].astype(np.uint8)) and np.array_equal(bits(t), bits(ref["t"]))
+    pin = np.concatenate([tri9, pl[:, 1:4], rng.uniform(-1, 1, (n, 3)).astype(np.float32)], 1)
+    assert np.array_equal(pkg.point_in_triangle(pin), orc.point_in_triangle(pin))
+
+
+def test_ray_box_primitive(pkg, orc):
+    rng = np.random.RandomState(13)
+    n = 200_000
+    lo = rng.uniform(-1, 0.5, (n, 3)).astype(np.float32)
+    hi = (lo + rng.uniform(0, 1, (n, 3))).astype(np.float32)
+    hi[:5000, 0] = lo[:5000, 0]  # zero-thickness boxes (F4)
+    box = np.concatenate([lo, hi], 1)
+    r = _random_rays(rng, n)
+    # zero / negative-zero direction components, origins on faces, inside, finite t
+    r[0:20000:2, 3] = 0.0
+    r[1:20000:2, 4] = -0.0
+    r[20000:30000, 3:5] = 0.0
+    r[30000:40000, 0] = lo[30000:40000, 0]
+    r[40000:50000, 0:3] = ((lo[40000:50000].astype(np.float64) + hi[40000:50000]) / 2).astype(np.float32)
+    r[50000:60000, 1] = hi[50000:60000, 1]
+    r[50000:60000, 4] = 0.0  # origin in the face plane AND parallel to it => 0/0 = NaN
+    r[::3, 6] = rng.uniform(0, 3, len(r[::3]))
+    t, hit, inside = pkg.ray_box(box, _rays(pkg, r))
+    ref = orc.ray_box(box, r)
+    assert np.array_equal(hit, ref["hit"].astype(np.uint8))
+    assert np.array_equal(bits(t), bits(ref["t"]))
+    assert np.array_equal(inside, ref["pad"].astype(np.uint8))
+    assert 0.05 < hit.mean() < 0.95 and inside.sum() > 5000
+
+
+def test_ray_sphere_primitive(pkg, orc):
+    rng = np.random.RandomState(14)
+    n = 100_000
+    sph = np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0.05, 1.5, (n, 1))], 1).astype(np.float32)
+    r = _random_rays(rng, n)
+    d = sph[:, 0:3] - r[:, 0:3]
+    r[: n // 2, 3:6] = (d / np.linalg.norm(d, axis=1, keepdims=True))[: n // 2]
+    r[::4, 6] = rng.uniform(0, 3, len(r[::4]))
+    t, hit, nrm = pkg.ray_sphere(sph, _rays(pkg, r))
+    ref = orc.ray_sphere(sph, r)
+    assert np.array_equal(hit, ref["hit"].astype(np.uint8)) and np.array_equal(bits(t), bits(ref["t"]))
+    m = hit == 1
+    assert np.array_equal(bits(nrm[m]), bits(ref["normal"][m]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# BoundingVolumeHierarchy::intersect, batched
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["triangle", "cube", "cornell", "monkey", "blob", "spheres"])
+def test_intersect_matches_golden_fixture(pkg, scene_data, name):
+    z = np.load(os.path.join(GOLDEN, f"hits_{name}.npz"))
+    sc = pkg.Scene(scene_data(name))
+    assert sc.num_levels() == int(z["levels"])
+    hits, normals = sc.intersect(_rays(pkg, z["rays"]))
+    assert np.array_equal(hits["hit"], z["hit"])
+    assert np.array_equal(bits(hits["t"]), z["t_bits"])
+    assert np.array_equal(hits["prim_id"], z["prim"])
+    assert np.array_equal(hits["material_id"], z["material"])
+    m = z["hit"] == 1
+    assert np.array_equal(bits(normals[m]), z["normal_bits"][m])
+
+
+@pytest.mark.parametrize("name", ["cube", "cornell", "monkey", "dodge", "blob"])
+def test_intersect_matches_oracle_fresh_rays(pkg, orc, scene_data, name):
+    sd = scene_data(name)
+    o = orc.OracleScene(sd)
+    _, boxes = o.nodes()
+    W = H = 96
+    cam = pkg.scenes.default_camera(W, H)
+    fam = rayfam.families(sd, boxes, orc.generate_rays(cam, W, H), rng=np.random.RandomState(99), n_random=4000)
+    sc = pkg.Scene(sd)
+    for k in sorted(fam):
+        hits, normals = sc.intersect(_rays(pkg, fam[k]))
+        _assert_hits_equal(hits, normals, o.intersect(fam[k]), f"{name}/{k}")
+
+
+def test_f4_false_misses_reproduced_on_gpu(pkg, scene_data):
+    sc = pkg.Scene(scene_data("cube"))
+    rays = pkg.as_rays(np.broadcast_to(np.float32(rayfam.F4_ORIGIN), (3, 3)), np.float32(rayfam.F4_DIRS))
+    hits, _ = sc.intersect(rays)
+    assert hits["hit"].tolist() == [0, 0, 0] and hits["prim_id"].tolist() == [pkg.NO_PRIM] * 3
+    assert bits(hits["t"]).tolist() == bits(np.float32([FMAX] * 3)).tolist()
+
+
+def test_miss_leaves_normals_untouched_and_empty_batch(pkg, scene_data):
+    sc = pkg.Scene(scene_data("cube"))
+    rays = pkg.as_rays([[5, 5, 5]], [[1, 0, 0]])
+    hits = np.zeros(1, pkg.HIT_DTYPE)
+    nrm = np.full((1, 3), 7.5, np.float32)
+    import ctypes as C
+
+    rc = pkg.lib().cgrt_intersect_batch(sc._h, rays.ctypes.data_as(C.c_void_p), 1, hits.ctypes.data_as(C.c_void_p),
+                                        nrm.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and hits["hit"][0] == 0 and nrm.tolist() == [[7.5, 7.5, 7.5]]  # HitInfo untouched on a miss
+    h, _ = sc.intersect(np.zeros(0, pkg.RAY_DTYPE))
+    assert len(h) == 0
+
+
+def test_mixed_meshes_and_spheres(pkg, orc, scene_data):
+    sd = scene_data("cornell")
+    sd2 = pkg.scenes.SceneData(pos_nrm=sd.pos_nrm, tri=sd.tri, tri_mesh=sd.tri_mesh, materials=sd.materials,
+                               spheres=np.float32([[0.1, -0.2, 0.0, 0.25, -1], [-0.3, 0.2, 0.1, 0.2, -1]]))
+    o, sc = orc.OracleScene(sd2), pkg.Scene(sd2)
+    W = H = 160
+    r = orc.generate_rays(pkg.scenes.default_camera(W, H), W, H)
+    hits, normals = sc.intersect(_rays(pkg, r))
+    ref = o.intersect(r)
+    _assert_hits_equal(hits, normals, ref, "cornell+spheres")
+    assert (hits["prim_id"][hits["hit"] == 1] >= sd.ntris).sum() > 100  # spheres were hit
+    # a sphere-over-triangle hit keeps the triangle's material (bvh.cpp:878-879 never writes it)
+    assert ((hits["prim_id"] >= sd.ntris) & (hits["prim_id"] != pkg.NO_PRIM) & (hits["material_id"] >= 0)).sum() > 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused primary frame (renderRayTracing's ray generation + intersect)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,W,H", [("cube", 256, 256), ("monkey", 1024, 1024), ("cornell", 480, 270), ("blob", 333, 217)])
+def test_trace_primary_bit_exact(pkg, orc, scene_data, name, W, H):
+    """Config 1 (cube 256^2) and config 2 (monkey 1024^2): bit-exact flag / t / id vs the CPU path."""
+    sd = scene_data(name)
+    cam = pkg.scenes.default_camera(W, H)
+    sc, o = pkg.Scene(sd), orc.OracleScene(sd)
+    rays = sc.generate_rays(cam, W, H)
+    assert np.array_equal(rays.view(np.float32).view(np.uint32).reshape(-1, 7), bits(orc.generate_rays(cam, W, H)))
+    hits, normals = sc.trace_primary(cam, W, H, want_normals=True)
+    _assert_hits_equal(hits, normals, o.intersect(rays), f"{name} {W}x{H}")
+    assert hits["hit"].sum() > 0.03 * W * H
+
+
+def test_trace_primary_tiles_partition_the_image(pkg, scene_data):
+    """Image tiling across ranks: ranks own disjoint 8x8 tiles whose union is the frame."""
+    sd = scene_data("monkey")
+    W, H = 500, 301  # ragged right/bottom tiles
+    cam = pkg.scenes.default_camera(W, H)
+    sc = pkg.Scene(sd)
+    full, _ = sc.trace_primary(cam, W, H)
+    for nranks in (2, 3, 8):
+        owner = np.full(W * H, -1)
+        merged = np.zeros(W * H, pkg.HIT_DTYPE)
+        for rank in range(nranks):
+            part, _ = sc.trace_primary(cam, W, H, rank=rank, nranks=nranks)
+            mine = ~np.isnan(part["t"])
+            assert np.all(owner[mine] == -1)
+            owner[mine] = rank
+            merged[mine] = part[mine]
+        assert np.all(owner >= 0)
+        assert merged.tobytes() == full.tobytes()
+        assert np.bincount(owner).min() > 0.8 * W * H / nranks
+    # sub-rectangle
+    part, _ = sc.trace_primary(cam, W, H, rect=(40, 16, 211, 100))
+    yy, xx = np.divmod(np.arange(W * H), W)
+    inside = (xx >= 40) & (xx < 211) & (yy >= 16) & (yy < 100)
+    assert np.array_equal(~np.isnan(part["t"]), inside)
+    assert part[inside].tobytes() == full[inside].tobytes()
+
+
+def test_counters_match_oracle_replay(pkg, orc, scene_data):
+    """cgrt_count_* (instrumented launch) == the oracle's count of the same traversal."""
+    sd = scene_data("monkey")
+    W = H = 200
+    cam = pkg.scenes.default_camera(W, H)
+    sc, o = pkg.Scene(sd), orc.OracleScene(sd)
+    _, cnt = o.intersect(orc.generate_rays(cam, W, H), counters=True)
+    got = sc.count_primary(cam, W, H)
+    assert got["rays"] == W * H
+    assert got["inner_visits"] == cnt["inner_visits"] and got["leaf_visits"] == cnt["leaf_visits"]
+    assert got["tri_tests"] == cnt["tri_tests"]
+    got2 = sc.count_batch(sc.generate_rays(cam, W, H))
+    assert {k: got2[k] for k in ("inner_visits", "leaf_visits", "tri_tests")} == {k: got[k] for k in ("inner_visits", "leaf_visits", "tri_tests")}
+
+
+# ---------------------------------------------------------------------------------------------------
+# dragon-scale: BASELINE.json full sizes, through size-independent properties + sampled oracle check
+# ---------------------------------------------------------------------------------------------------
+def test_dragon_87k_full_frame_vs_oracle(pkg, orc):
+    """87 K triangles (the report's dragon size), 640x360 frame, every ray against the oracle."""
+    sd = pkg.scenes.make_dragon(87_000)
+    W, H = 640, 360
+    cam = pkg.scenes.default_camera(W, H)
+    sc, o = pkg.Scene(sd), orc.OracleScene(sd)
+    hits, normals = sc.trace_primary(cam, W, H, want_normals=True)
+    _assert_hits_equal(hits, normals, o.intersect(sc.generate_rays(cam, W, H)), "dragon87k")
+
+
+def test_dragon_800k_1080p_properties(pkg, orc):
+    """Config 4 at full size.  Checked: (1) every 16th row against the oracle; (2) determinism;
+    (3) tile partition invariance; (4) every reported hit re-verified by the element-wise triangle primitive:
+    the reported triangle is hit at exactly the reported t, and nothing reports t beyond FLT_MAX."""
+    sd = pkg.scenes.make_dragon(800_000)
+    W, H = 1920, 1080
+    cam = pkg.scenes.default_camera(W, H)
+    sc = pkg.Scene(sd)
+    assert sc.num_levels() == 12
+    hits, _ = sc.trace_primary(cam, W, H)
+    again, _ = sc.trace_primary(cam, W, H)
+    assert hits.tobytes() == again.tobytes()
+    o = orc.OracleScene(sd)
+    rows = np.arange(0, H, 16)
+    idx = (rows[:, None] * W + np.arange(W)[None, :]).reshape(-1)
+    rays = sc.generate_rays(cam, W, H)
+    ref = o.intersect(rays[idx])
+    _assert_hits_equal(hits[idx], None, ref, "dragon800k rows")
+    m = hits["hit"] == 1
+    assert 0.1 < m.mean() < 0.9
+    # re-verify every hit with the primitive on the reported triangle
+    prim = hits["prim_id"][m]
+    v = sd.pos_nrm[sd.tri[prim].reshape(-1)].reshape(-1, 3, 6)
+    tri18 = np.concatenate([v[:, :, 0:3].reshape(-1, 9), v[:, :, 3:6].reshape(-1, 9)], 1)
+    t, hit, _ = pkg.ray_triangle(tri18, rays[m])
+    assert hit.all() and np.array_equal(bits(t), bits(hits["t"][m]))
+    part = [sc.trace_primary(cam, W, H, rank=r, nranks=2)[0] for r in range(2)]
+    own0 = ~np.isnan(part[0]["t"])
+    merged = np.where(own0, part[0], part[1])
+    assert merged.tobytes() == hits.tobytes()
