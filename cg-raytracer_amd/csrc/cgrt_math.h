@@ -42,20 +42,11 @@ CGRT_HD float dot(F3 a, F3 b) {
 // glm::cross
 CGRT_HD F3 cross(F3 a, F3 b) { return f3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 
-CGRT_HD float sqrt_ieee(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return __builtin_sqrtf(x);
-#endif
-}
-CGRT_HD double sqrt_ieee_d(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __dsqrt_rn(x);
-#else
-    return __builtin_sqrt(x);
-#endif
-}
+// Correctly rounded square roots.  __builtin_sqrtf lowers to llvm.sqrt.f32, which hipcc expands to the
+// IEEE-correct refinement sequence under -fhip-fp32-correctly-rounded-divide-sqrt (its default).
+// NOT __fsqrt_rn / __builtin_amdgcn_sqrtf: those emit a bare v_sqrt_f32 (1 ulp), which broke parity.
+CGRT_HD float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+CGRT_HD double sqrt_ieee_d(double x) { return __builtin_sqrt(x); }
 // glm::normalize(v) = v * inversesqrt(dot(v, v)), inversesqrt(x) = 1.0f / sqrt(x)
 CGRT_HD F3 normalize(F3 v) { return scale(v, 1.0f / sqrt_ieee(dot(v, v))); }
 CGRT_HD float length(F3 v) { return sqrt_ieee(dot(v, v)); }

@@ -54,3 +54,12 @@ def scene_data(pkg):
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def same_bits(a, b):
+    """Bit-pattern equality of float32 arrays; NaNs compare equal to NaNs (x86 SSE produces the negative
+    default NaN 0xffc00000 for 0/0, gfx950 the positive 0x7fc00000 -- the payload is not part of any result
+    the reference can observe, every comparison with a NaN being false either way)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
