@@ -83,7 +83,7 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/cgrt.h declares
 EXPORTS = [
-    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
+    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
     "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_count_primary", "cgrt_count_batch", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
     L.cgrt_scene_destroy.restype = None
     for f in (L.cgrt_num_levels, L.cgrt_num_nodes):
         f.argtypes = [vp]
+    L.cgrt_set_leaf_accel.argtypes = [i32, i32]
+    L.cgrt_num_subnodes.argtypes = [vp]
     L.cgrt_get_nodes.argtypes = [vp, vp, vp]
     L.cgrt_leaf_prims.argtypes = [vp, i32, vp, u32]
     L.cgrt_leaf_prims.restype = C.c_int64
@@ -161,6 +163,11 @@ def record_sizes() -> dict:
     return dict(zip(("node", "tri", "sub", "hit"), (int(x.value) for x in v)))
 
 
+def set_leaf_accel(enabled: bool = True, sub_leaf_tris: int = 0) -> None:
+    """Process-wide build option for scenes created afterwards (results are identical either way)."""
+    _check(lib().cgrt_set_leaf_accel(1 if enabled else 0, sub_leaf_tris))
+
+
 def device_count() -> int:
     return int(lib().cgrt_device_count())
 
@@ -194,6 +201,9 @@ class Scene:
     # ---- introspection ----
     def num_levels(self) -> int:
         return int(lib().cgrt_num_levels(self._h))
+
+    def num_subnodes(self) -> int:
+        return int(lib().cgrt_num_subnodes(self._h))
 
     def build_seconds(self) -> float:
         return float(lib().cgrt_build_seconds(self._h))

@@ -14,7 +14,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <utility>
 
 #include "cgrt_math.h"
@@ -80,9 +82,169 @@ struct Builder {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// In-leaf accelerator (DESIGN.md "In-leaf accelerator").
+//
+// The reference caps its tree at 12 levels, so big meshes end in fat leaves (~390 triangles at 800 K)
+// that intersectLeaf scans linearly (bvh.cpp:535-553).  The scan's outcome is a pure function of the
+// leaf's triangle SET plus each triangle's scan position: the smallest accepted t wins, equal t goes to
+// the earlier scan position, and an origin-on-plane acceptance (t = 0, ray_tracing.cpp:43-47) goes to
+// the LAST such triangle.  So the kernel may test the triangles in any order -- and skip any triangle
+// that provably cannot be accepted -- as long as it applies that rule.  This builds, per reference
+// leaf, a binary BVH (surface-area heuristic, full sweep on every axis) used only to skip triangles
+// whose padded box the ray misses or enters beyond the current best t.  The reference topology, its
+// visit order and its culling decisions above the leaves are untouched.
+//
+// Depth is bounded (SUB_MAX_DEPTH) because the per-ray stack is a fixed LDS slice: a split is only
+// eligible if both sides still fit under the remaining depth.
+struct SubBuilder {
+    std::vector<TriRecord>& tris;
+    std::vector<TriNormals>& nrms;
+    std::vector<SubNode>& nodes;
+    int leaf_tris;
+    // per-leaf scratch
+    std::vector<Box6> tb;        // triangle boxes (leaf-local)
+    std::vector<float> cen[3];
+    std::vector<uint32_t> idx;   // permutation being built (leaf-local indices)
+    std::vector<float> rarea;
+
+    static Box6 empty_box() {
+        Box6 b;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = std::numeric_limits<float>::infinity();
+            b.hi[a] = -std::numeric_limits<float>::infinity();
+        }
+        return b;
+    }
+    static void grow(Box6& b, const Box6& o) {
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = std::min(b.lo[a], o.lo[a]);
+            b.hi[a] = std::max(b.hi[a], o.hi[a]);
+        }
+    }
+    static float half_area(const Box6& b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+    Box6 range_box(uint32_t b, uint32_t e) const {
+        Box6 r = empty_box();
+        for (uint32_t i = b; i < e; i++) grow(r, tb[idx[i]]);
+        return r;
+    }
+    static uint64_t capacity(int depth_left, int leaf_tris) { return (uint64_t)leaf_tris << depth_left; }
+
+    // Splits idx[b, e) and returns the position of the split; depth_left >= 1 levels remain below.
+    uint32_t split(uint32_t b, uint32_t e, int depth_left) {
+        const uint32_t n = e - b;
+        const uint64_t cap = capacity(depth_left - 1, leaf_tris);  // what one child may still hold
+        const uint32_t kmin = (uint32_t)std::max<int64_t>(1, (int64_t)n - (int64_t)cap);
+        const uint32_t kmax = (uint32_t)std::min<uint64_t>(n - 1, cap);
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1;
+        uint32_t best_k = n / 2;
+        std::vector<uint32_t> ord[3];
+        rarea.resize(n);
+        for (int a = 0; a < 3; a++) {
+            ord[a].assign(idx.begin() + b, idx.begin() + e);
+            std::stable_sort(ord[a].begin(), ord[a].end(), [&](uint32_t p, uint32_t q) { return cen[a][p] < cen[a][q]; });
+            Box6 acc = empty_box();
+            for (uint32_t i = n; i-- > 1;) {
+                grow(acc, tb[ord[a][i]]);
+                rarea[i] = half_area(acc);
+            }
+            acc = empty_box();
+            for (uint32_t k = 1; k < n; k++) {
+                grow(acc, tb[ord[a][k - 1]]);
+                if (k < kmin || k > kmax) continue;
+                const float cost = half_area(acc) * (float)k + rarea[k] * (float)(n - k);  // surface-area heuristic
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_k = k;
+                }
+            }
+        }
+        if (best_axis < 0)  // NaN geometry: any split inside [kmin, kmax] keeps the depth bound
+            best_k = std::min(std::max(n / 2, kmin), kmax);
+        else
+            std::copy(ord[best_axis].begin(), ord[best_axis].end(), idx.begin() + b);
+        return b + best_k;
+    }
+
+    // Builds the subtree over idx[b, e) (more than leaf_tris triangles) and returns its node index.
+    uint32_t build(uint32_t base, uint32_t b, uint32_t e, int depth_left) {
+        const uint32_t me = (uint32_t)nodes.size();
+        nodes.push_back(SubNode());
+        const uint32_t m = split(b, e, depth_left);
+        const Box6 lb = range_box(b, m), rb = range_box(m, e);
+        uint32_t ref[2], cnt[2];
+        const uint32_t rb_[2] = {b, m}, re_[2] = {m, e};
+        for (int c = 0; c < 2; c++) {
+            const uint32_t cn = re_[c] - rb_[c];
+            // a child becomes a run of records when it is small enough or no depth is left
+            if (cn <= (uint32_t)leaf_tris || depth_left - 1 <= 0) {
+                ref[c] = REF_LEAF | (base + rb_[c]);
+                cnt[c] = cn;
+            } else {
+                ref[c] = build(base, rb_[c], re_[c], depth_left - 1);
+                cnt[c] = 0;
+            }
+        }
+        SubNode& N = nodes[me];
+        std::memcpy(N.box0, &lb, 24);
+        std::memcpy(N.box1, &rb, 24);
+        N.ref0 = ref[0];
+        N.ref1 = ref[1];
+        N.cnt0 = cnt[0];
+        N.cnt1 = cnt[1];
+        return me;
+    }
+
+    void run(LeafRec& L) {
+        const uint32_t n = L.count;
+        if (n <= (uint32_t)leaf_tris) return;  // small leaf: all candidates are tested
+        int lt = leaf_tris;
+        while (capacity(SUB_MAX_DEPTH, lt) < n) lt *= 2;  // giant leaf: coarser sub-leaves, same depth bound
+        const int saved = leaf_tris;
+        leaf_tris = lt;
+        tb.resize(n);
+        idx.resize(n);
+        for (int a = 0; a < 3; a++) cen[a].resize(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const TriRecord& T = tris[L.first + i];
+            for (int a = 0; a < 3; a++) {
+                const float lo = std::min(T.v0[a], std::min(T.v1[a], T.v2[a]));
+                const float hi = std::max(T.v0[a], std::max(T.v1[a], T.v2[a]));
+                tb[i].lo[a] = lo;
+                tb[i].hi[a] = hi;
+                cen[a][i] = 0.5f * lo + 0.5f * hi;
+            }
+            idx[i] = i;
+        }
+        L.sub_root = build(L.first, 0, n, SUB_MAX_DEPTH);
+        leaf_tris = saved;
+        // apply the permutation to the records (scan_k keeps every triangle's reference scan position)
+        std::vector<TriRecord> t2(n);
+        std::vector<TriNormals> n2(n);
+        for (uint32_t i = 0; i < n; i++) {
+            t2[i] = tris[L.first + idx[i]];
+            n2[i] = nrms[L.first + idx[i]];
+        }
+        std::copy(t2.begin(), t2.end(), tris.begin() + L.first);
+        std::copy(n2.begin(), n2.end(), nrms.begin() + L.first);
+    }
+};
+
+void build_leaf_accelerators(BuiltBvh& out, int leaf_tris) {
+    SubBuilder sb{out.tris, out.tri_normals, out.subnodes, leaf_tris < 1 ? 1 : leaf_tris, {}, {}, {}, {}};
+    for (LeafRec& L : out.leaves) sb.run(L);
+}
+
 }  // namespace
 
-bool build_reference_bvh(const HostScene& sc, BuiltBvh& out, std::string& err) {
+bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh& out, std::string& err) {
     auto t_start = std::chrono::steady_clock::now();
     out = BuiltBvh();
     // ---- validation (the reference has none; out-of-range input would be UB there) ----
@@ -239,7 +401,7 @@ bool build_reference_bvh(const HostScene& sc, BuiltBvh& out, std::string& err) {
                 T.D = D;
                 T.prim_id = p;
                 T.mesh_id = sc.tri_mesh[p];
-                T.pad = 0;
+                T.scan_k = k;
                 TriNormals& N = out.tri_normals[w];
                 std::memcpy(N.n1, a + 3, 12);
                 std::memcpy(N.n2, b + 3, 12);
@@ -255,6 +417,12 @@ bool build_reference_bvh(const HostScene& sc, BuiltBvh& out, std::string& err) {
             P.pad[0] = P.pad[1] = 0;
         }
     }
+    for (size_t v = 0; v < sc.pos_nrm.size(); v += 6)
+        for (int a = 0; a < 3; a++) {
+            const float c = std::fabs(sc.pos_nrm[v + a]);
+            if (c > out.scene_absmax) out.scene_absmax = c;  // NaN coordinates never raise it
+        }
+    if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
     out.root_box = out.nodes[0].box;
     out.root_ref = ref_of(0);
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

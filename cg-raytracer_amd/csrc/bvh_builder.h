@@ -38,13 +38,20 @@ struct BuiltBvh {
     std::vector<int> node_to_ref_index;  // node -> packet index (inner) or leaf index (leaf)
     std::vector<TriRecord> tris;         // leaf order
     std::vector<TriNormals> tri_normals;
+    std::vector<SubNode> subnodes;       // in-leaf accelerators of all leaves (empty when disabled)
+    float scene_absmax = 0;              // largest |vertex coordinate|
     std::vector<SphereRecord> spheres;
     Box6 root_box{};
     uint32_t root_ref = REF_NONE;
     double build_seconds = 0;
 };
 
+struct BuildOptions {
+    bool leaf_accel = true;  // build the in-leaf accelerator (results are identical either way)
+    int sub_leaf_tris = SUB_LEAF_TRIS;
+};
+
 // Returns false and sets err on invalid input.
-bool build_reference_bvh(const HostScene& scene, BuiltBvh& out, std::string& err);
+bool build_reference_bvh(const HostScene& scene, const BuildOptions& opt, BuiltBvh& out, std::string& err);
 
 }  // namespace cgrt

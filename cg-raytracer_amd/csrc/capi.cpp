@@ -24,6 +24,7 @@ static_assert(sizeof(CgrtHit) == sizeof(CgrtHitDev), "CgrtHit layout");
 namespace {
 
 thread_local std::string g_err;
+BuildOptions g_build_options;  // process-wide, set through cgrt_set_leaf_accel before cgrt_scene_create
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -116,12 +117,13 @@ struct CgrtScene {
     void* d_tris = nullptr;
     void* d_tri_normals = nullptr;
     void* d_spheres = nullptr;
+    void* d_subnodes = nullptr;
     unsigned long long* d_counters = nullptr;
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_packets, d_leaves, d_tris, d_tri_normals, d_spheres, (void*)d_counters})
+        for (void* p : {d_packets, d_leaves, d_tris, d_tri_normals, d_spheres, d_subnodes, (void*)d_counters})
             if (p) (void)hipFree(p);
     }
 };
@@ -175,7 +177,7 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
         s->device = device;
         s->ntris = ntris;
         std::string err;
-        if (!build_reference_bvh(hs, s->bvh, err)) {
+        if (!build_reference_bvh(hs, g_build_options, s->bvh, err)) {
             delete s;
             return fail(err.find("deeper") != std::string::npos ? CGRT_E_LIMIT : CGRT_E_ARG, err);
         }
@@ -186,7 +188,7 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
         uint64_t total = 0;
         if ((rc = upload(s->bvh.packets, &s->d_packets, total)) || (rc = upload(s->bvh.leaves, &s->d_leaves, total)) ||
             (rc = upload(s->bvh.tris, &s->d_tris, total)) || (rc = upload(s->bvh.tri_normals, &s->d_tri_normals, total)) ||
-            (rc = upload(s->bvh.spheres, &s->d_spheres, total))) {
+            (rc = upload(s->bvh.spheres, &s->d_spheres, total)) || (rc = upload(s->bvh.subnodes, &s->d_subnodes, total))) {
             delete s;
             return rc;
         }
@@ -202,6 +204,8 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
         D.tris = static_cast<const TriRecord*>(s->d_tris);
         D.tri_normals = static_cast<const TriNormals*>(s->d_tri_normals);
         D.spheres = static_cast<const SphereRecord*>(s->d_spheres);
+        D.subnodes = static_cast<const SubNode*>(s->d_subnodes);
+        D.scene_eps = s->bvh.scene_absmax * 1.52587890625e-05f;  // 2^-16
         D.root_box = s->bvh.root_box;
         D.root_ref = s->bvh.root_ref;
         D.ntris = ntris;
@@ -216,6 +220,14 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
 }
 
 void cgrt_scene_destroy(CgrtScene* scene) { delete scene; }
+
+int cgrt_set_leaf_accel(int enabled, int sub_leaf_tris) {
+    if (sub_leaf_tris < 0 || sub_leaf_tris > 64) return fail(CGRT_E_ARG, "sub_leaf_tris must be in 0..64 (0 = default)");
+    g_build_options.leaf_accel = enabled != 0;
+    g_build_options.sub_leaf_tris = sub_leaf_tris ? sub_leaf_tris : SUB_LEAF_TRIS;
+    return CGRT_OK;
+}
+int cgrt_num_subnodes(const CgrtScene* s) { return s ? (int)s->bvh.subnodes.size() : fail(CGRT_E_ARG, "scene is NULL"); }
 
 int cgrt_num_levels(const CgrtScene* s) { return s ? s->bvh.levels : fail(CGRT_E_ARG, "scene is NULL"); }
 int cgrt_num_nodes(const CgrtScene* s) { return s ? (int)s->bvh.nodes.size() : fail(CGRT_E_ARG, "scene is NULL"); }
@@ -246,7 +258,7 @@ int64_t cgrt_leaf_prims(const CgrtScene* s, int node, uint32_t* out, uint32_t ca
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes) {
     if (node_bytes) *node_bytes = sizeof(NodePacket);
     if (tri_bytes) *tri_bytes = sizeof(TriRecord);
-    if (sub_bytes) *sub_bytes = 0;
+    if (sub_bytes) *sub_bytes = sizeof(SubNode);
     if (hit_bytes) *hit_bytes = sizeof(CgrtHit);
 }
 

@@ -32,6 +32,19 @@ struct LeafRec {
 };
 static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
 
+// One node of a leaf's in-leaf accelerator (a binary BVH over the triangles of ONE reference leaf,
+// DESIGN.md "In-leaf accelerator"), both child boxes inline (64 B).  A child is another SubNode
+// (ref = index) or a run of TriRecords (ref = REF_LEAF | first record, cnt = number of records).
+struct alignas(16) SubNode {
+    float box0[6];
+    float box1[6];
+    uint32_t ref0, ref1;
+    uint32_t cnt0, cnt1;
+};
+static_assert(sizeof(SubNode) == 64, "SubNode must be 64 B");
+static const int SUB_MAX_DEPTH = 12;   // per-ray sub-stack never exceeds this many entries
+static const int SUB_LEAF_TRIS = 4;    // target triangles per sub-leaf
+
 // One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent
 // trianglePlane (ray_tracing.cpp:74-82) evaluated once on the host with the reference's arithmetic.
 struct alignas(16) TriRecord {
@@ -42,7 +55,7 @@ struct alignas(16) TriRecord {
     float D;
     uint32_t prim_id;  // global triangle index
     uint32_t mesh_id;  // -> hitInfo.material
-    uint32_t pad;
+    uint32_t scan_k;   // position in the reference leaf's scan order (bvh.cpp:538-551); decides ties
 };
 static_assert(sizeof(TriRecord) == 64, "TriRecord must be 64 B");
 
@@ -68,7 +81,9 @@ struct SceneDev {
     const TriRecord* tris;
     const TriNormals* tri_normals;  // indexed like tris (leaf order)
     const SphereRecord* spheres;
+    const SubNode* subnodes;
     Box6 root_box;
+    float scene_eps;    // 2^-16 * largest |coordinate| of the scene: conservative slack of the in-leaf boxes
     uint32_t root_ref;  // REF_NONE when the scene has no meshes (bvh.cpp:870)
     uint32_t ntris;
     uint32_t nspheres;

@@ -9,8 +9,11 @@
 // on pop iff ray.t < tSecond -- the reference's `hitFirst && ray.t < tSecond` (bvh.cpp:581-585), since
 // ray.t only changes when a triangle is accepted.  A child whose box test failed (t = -1) is dropped,
 // and an origin strictly inside both child boxes visits both unconditionally (:685-688).
-// The per-lane stack (<= 11 entries, bvh.cpp:48) lives in LDS, lane-interleaved so that every access
-// is bank-conflict free; runtime-indexed register arrays would go to scratch.
+// Inside a reference leaf the linear scan of intersectLeaf (bvh.cpp:535-553) is replaced by an order-free
+// but outcome-identical evaluation over a per-leaf binary BVH (scan_leaf below, DESIGN.md "In-leaf accelerator").
+// The per-lane stack (<= 11 deferred children, bvh.cpp:48, plus <= 12 in-leaf entries) lives in LDS,
+// lane-interleaved so that every access is bank-conflict free; runtime-indexed register arrays would go
+// to scratch.
 //
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (no FMA contraction), default IEEE div/sqrt,
 // denormals on -- see cgrt_math.h for why.
@@ -23,7 +26,9 @@
 namespace cgrt {
 
 #define CGRT_BLOCK 256
-#define CGRT_STACK (MAX_LEVELS)
+// Per-lane LDS stack, in 4-byte slots: a deferred reference child takes 2 slots (ref, tSecond), at most
+// MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 1 slot (node index), at most SUB_MAX_DEPTH.
+#define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + SUB_MAX_DEPTH)
 
 struct LaneCounters {
     uint32_t inner = 0, leaf = 0, tri = 0, sub = 0;
@@ -31,12 +36,187 @@ struct LaneCounters {
 
 __device__ __forceinline__ F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
+// Per-ray constants of the CONSERVATIVE slab test used inside leaves (never for the reference's own
+// box tests).  The test must never reject a box that contains a point the reference's float
+// arithmetic could accept as a hit, so every box is widened by eps = 2^-16 * (|origin|max + |scene|max)
+// -- 256x the rounding unit at the magnitudes involved -- and zero/tiny direction components are
+// clamped away from zero (2^-40 relative), which moves the ray by far less than eps over any distance
+// at which something can be hit.  Rays outside the range where that argument holds (non-finite
+// components, |d|max or |o|max beyond 2^+-40, NaN t) are flagged irregular and test every triangle of a
+// leaf instead.  DESIGN.md "In-leaf accelerator" has the full argument.
+struct RayPre {
+    F3 inv, oin, oif;
+    bool sx, sy, sz;
+    bool regular;
+};
+
+__device__ __forceinline__ RayPre make_raypre(const SceneDev& S, const F3 o, const F3 d, const float t) {
+    RayPre P;
+    const float dmax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    const float big = 1.099511627776e12f, small = 9.094947017729282e-13f;  // 2^40, 2^-40
+    const bool finite = (fabsf(o.x) <= big) && (fabsf(o.y) <= big) && (fabsf(o.z) <= big) && (fabsf(d.x) <= big) &&
+                        (fabsf(d.y) <= big) && (fabsf(d.z) <= big);  // false for NaN and +-inf too
+    P.regular = finite && (dmax >= small) && !(t != t) && (S.scene_eps <= 16777216.0f);
+    const float fl = dmax * small;
+    const float dx = fabsf(d.x) >= fl ? d.x : copysignf(fl, d.x);
+    const float dy = fabsf(d.y) >= fl ? d.y : copysignf(fl, d.y);
+    const float dz = fabsf(d.z) >= fl ? d.z : copysignf(fl, d.z);
+    P.inv = f3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    P.sx = dx < 0;
+    P.sy = dy < 0;
+    P.sz = dz < 0;
+    const float eps = S.scene_eps + 1.52587890625e-05f * omax;  // 2^-16
+    const F3 oi = f3(o.x * P.inv.x, o.y * P.inv.y, o.z * P.inv.z);
+    const F3 sl = f3(eps * fabsf(P.inv.x), eps * fabsf(P.inv.y), eps * fabsf(P.inv.z));
+    P.oin = f3(oi.x + sl.x, oi.y + sl.y, oi.z + sl.z);
+    P.oif = f3(oi.x - sl.x, oi.y - sl.y, oi.z - sl.z);
+    (void)omax;
+    return P;
+}
+
+// Conservative [tn, tf] of the widened box; explicit fma: this is NOT reference arithmetic.
+__device__ __forceinline__ void slab_cons(const RayPre& P, const F3 lo, const F3 hi, float& tn, float& tf) {
+    const float nx = P.sx ? hi.x : lo.x, fx = P.sx ? lo.x : hi.x;
+    const float ny = P.sy ? hi.y : lo.y, fy = P.sy ? lo.y : hi.y;
+    const float nz = P.sz ? hi.z : lo.z, fz = P.sz ? lo.z : hi.z;
+    tn = fmaxf(fmaxf(__builtin_fmaf(nx, P.inv.x, -P.oin.x), __builtin_fmaf(ny, P.inv.y, -P.oin.y)), __builtin_fmaf(nz, P.inv.z, -P.oin.z));
+    tf = fminf(fminf(__builtin_fmaf(fx, P.inv.x, -P.oif.x), __builtin_fmaf(fy, P.inv.y, -P.oif.y)), __builtin_fmaf(fz, P.inv.z, -P.oif.z));
+}
+
+// State of one reference leaf's scan, order-free form (see bvh_builder.cpp "In-leaf accelerator"):
+//   regular acceptances keep the lexicographic minimum of (t, scan position), starting from the entry
+//   ray.t with strict <;  origin-on-plane acceptances (t = 0 without a guard) keep the LAST scan position.
+struct LeafScan {
+    float best_t;
+    int best_k;
+    uint32_t best_rec;
+    int onp_k;
+    uint32_t onp_rec;
+};
+
+// intersectRayWithTriangle (ray_tracing.cpp:86-114) for record `rec`, reference arithmetic.
+__device__ __forceinline__ void test_record(const SceneDev& S, const uint32_t rec, const F3 o, const F3 d, LeafScan& L) {
+    const float4* q = reinterpret_cast<const float4*>(S.tris + rec);
+    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    const F3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.w, b.x, b.y), v2 = f3(b.z, b.w, c.x);
+    const F3 n = f3(c.y, c.z, c.w);
+    const float D = e.x;
+    const int k = (int)__float_as_uint(e.w);
+    const float on = dot(o, n);
+    if (on == D) {  // ray_tracing.cpp:43-47: t = 0, no t < ray.t guard; the last one scanned wins
+        const F3 p = add(o, scale(d, 0.0f));
+        if (point_in_triangle(v0, v1, v2, n, p) && k > L.onp_k) {
+            L.onp_k = k;
+            L.onp_rec = rec;
+        }
+        return;
+    }
+    const float den = dot(d, n);
+    if (den == 0) return;
+    const float tt = (D - on) / den;
+    if (tt < 0) return;
+    // ray_tracing.cpp:65 `t >= ray.t` against the scan's running minimum; equal t is taken only from
+    // an EARLIER scan position (the reference would have met that triangle first)
+    if (tt >= L.best_t && !(tt == L.best_t && k < L.best_k)) return;
+    const F3 p = add(o, scale(d, tt));
+    if (!point_in_triangle(v0, v1, v2, n, p)) return;
+    L.best_t = tt;
+    L.best_k = k;
+    L.best_rec = rec;
+}
+
+// intersectLeaf (bvh.cpp:535-553) for one ray.
+template <bool COUNT>
+__device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, const F3 o, const F3 d, const RayPre& P, float& t,
+                                          uint32_t& hit_rec, uint32_t* __restrict__ stk, int sp, LaneCounters& cnt) {
+    LeafScan L;
+    L.best_t = t;
+    L.best_k = -1;
+    L.best_rec = REF_NONE;
+    L.onp_k = -1;
+    L.onp_rec = REF_NONE;
+    if (LR.sub_root == REF_NONE || !P.regular) {
+        if (COUNT) cnt.tri += LR.count;
+        for (uint32_t i = 0; i < LR.count; i++) test_record(S, LR.first + i, o, d, L);
+    } else {
+        const int sp0 = sp;
+        uint32_t cur = LR.sub_root;
+        for (;;) {
+            if (COUNT) cnt.sub++;
+            const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
+            const float4 a = q[0], b = q[1], c = q[2];
+            const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
+            float tn0, tf0, tn1, tf1;
+            slab_cons(P, f3(a.x, a.y, a.z), f3(a.w, b.x, b.y), tn0, tf0);
+            slab_cons(P, f3(b.z, b.w, c.x), f3(c.y, c.z, c.w), tn1, tf1);
+            // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
+            // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
+            const float tc = fmaxf(L.best_t, 0.0f);
+            bool h0 = (tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc);
+            bool h1 = (tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc);
+            uint32_t r0 = m.x, r1 = m.y, c0 = m.z, c1 = m.w;
+            if (h0 && h1 && tn1 < tn0) {  // nearer child first
+                const uint32_t tr = r0, tc = c0;
+                r0 = r1;
+                c0 = c1;
+                r1 = tr;
+                c1 = tc;
+                const float tt = tn0;
+                tn0 = tn1;
+                tn1 = tt;
+            } else if (!h0 && h1) {
+                r0 = r1;
+                c0 = c1;
+                tn0 = tn1;
+                h0 = true;
+                h1 = false;
+            }
+            uint32_t next = REF_NONE;
+            if (h0) {
+                if (r0 & REF_LEAF) {
+                    if (COUNT) cnt.tri += c0;
+                    const uint32_t f = r0 & ~REF_LEAF;
+                    for (uint32_t i = 0; i < c0; i++) test_record(S, f + i, o, d, L);
+                } else {
+                    next = r0;
+                }
+            }
+            if (h1 && (tn1 <= fmaxf(L.best_t, 0.0f))) {  // re-checked: the nearer child may have tightened best_t
+                if (r1 & REF_LEAF) {
+                    if (COUNT) cnt.tri += c1;
+                    const uint32_t f = r1 & ~REF_LEAF;
+                    for (uint32_t i = 0; i < c1; i++) test_record(S, f + i, o, d, L);
+                } else if (next == REF_NONE) {
+                    next = r1;
+                } else {
+                    stk[sp * CGRT_BLOCK] = r1;
+                    ++sp;
+                }
+            }
+            if (next == REF_NONE) {
+                if (sp == sp0) break;
+                --sp;
+                next = stk[sp * CGRT_BLOCK];
+            }
+            cur = next;
+        }
+    }
+    if (L.onp_k >= 0) {
+        t = 0.0f;
+        hit_rec = L.onp_rec;
+    } else if (L.best_k >= 0) {
+        t = L.best_t;
+        hit_rec = L.best_rec;
+    }
+}
+
 // Ordered closest-hit walk of the reference tree for one ray.
 //   t        in/out ray.t
-//   hit_rec  leaf-order index of the last accepted triangle (REF_NONE if none)
+//   hit_rec  index of the last accepted triangle's TriRecord (REF_NONE if none)
 template <bool COUNT>
 __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
-                                          uint32_t* __restrict__ stk_ref, float* __restrict__ stk_t, LaneCounters& cnt) {
+                                          uint32_t* __restrict__ stk, LaneCounters& cnt) {
     uint32_t cur = REF_NONE;
     if (S.root_ref != REF_NONE) {
         // intersectDataStructure, bvh.cpp:831-844 (the box test's write to ray.t is undone there)
@@ -45,14 +225,16 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F
         float tb;
         if (starts_in_box(o, lo, hi) || ray_box(lo, hi, o, d, t, tb)) cur = S.root_ref;
     }
+    if (cur == REF_NONE) return;
+    const RayPre P = make_raypre(S, o, d, t);
     int sp = 0;
     for (;;) {
         if (cur == REF_NONE) {
             bool found = false;
             while (sp > 0) {
-                --sp;
-                const float ts = stk_t[sp * CGRT_BLOCK];
-                const uint32_t r = stk_ref[sp * CGRT_BLOCK];
+                sp -= 2;
+                const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
+                const uint32_t r = stk[sp * CGRT_BLOCK];
                 if (!(t < ts)) {  // bvh.cpp:582: skip the deferred child iff ray.t < tSecond
                     cur = r;
                     found = true;
@@ -62,19 +244,8 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F
             if (!found) break;
         }
         if (cur & REF_LEAF) {
-            // intersectLeaf, bvh.cpp:535-553: linear scan in leaf order
-            const LeafRec L = S.leaves[cur & ~REF_LEAF];
-            if (COUNT) {
-                cnt.leaf++;
-                cnt.tri += L.count;
-            }
-            for (uint32_t k = 0; k < L.count; k++) {
-                const float4* q = reinterpret_cast<const float4*>(S.tris + (L.first + k));
-                const float4 a = q[0], b = q[1], c = q[2], e = q[3];
-                const F3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.w, b.x, b.y), v2 = f3(b.z, b.w, c.x);
-                const F3 n = f3(c.y, c.z, c.w);
-                if (ray_triangle_geom(v0, v1, v2, n, e.x, o, d, t)) hit_rec = L.first + k;
-            }
+            if (COUNT) cnt.leaf++;
+            scan_leaf<COUNT>(S, S.leaves[cur & ~REF_LEAF], o, d, P, t, hit_rec, stk, sp, cnt);
             cur = REF_NONE;
             continue;
         }
@@ -125,9 +296,9 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F
             }
         }
         if (second != REF_NONE) {
-            stk_ref[sp * CGRT_BLOCK] = second;
-            stk_t[sp * CGRT_BLOCK] = tsec;
-            ++sp;
+            stk[sp * CGRT_BLOCK] = second;
+            stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
+            sp += 2;
         }
         cur = first;
     }
@@ -212,8 +383,7 @@ __device__ __forceinline__ bool tile_pixel(const FrameDev& F, uint32_t wave_glob
 template <bool COUNT>
 __global__ __launch_bounds__(CGRT_BLOCK) void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits,
                                                               float* __restrict__ normals, unsigned long long* counters) {
-    __shared__ uint32_t s_ref[CGRT_STACK * CGRT_BLOCK];
-    __shared__ float s_t[CGRT_STACK * CGRT_BLOCK];
+    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = blockIdx.x * (CGRT_BLOCK / 64) + (threadIdx.x >> 6);
     int x = 0, y = 0;
@@ -224,7 +394,7 @@ __global__ __launch_bounds__(CGRT_BLOCK) void k_trace_primary(SceneDev S, Camera
         primary_ray(C, F.W, F.H, x, y, o, d);
         float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
         uint32_t hit_rec = REF_NONE;
-        walk_tree<COUNT>(S, o, d, t, hit_rec, s_ref + threadIdx.x, s_t + threadIdx.x, cnt);
+        walk_tree<COUNT>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
         const size_t pix = (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
@@ -235,8 +405,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(CGRT_BLOCK) void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                                             unsigned long long* counters) {
-    __shared__ uint32_t s_ref[CGRT_STACK * CGRT_BLOCK];
-    __shared__ float s_t[CGRT_STACK * CGRT_BLOCK];
+    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
     const unsigned long long i = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
     const bool active = i < n;
     LaneCounters cnt;
@@ -245,7 +414,7 @@ __global__ __launch_bounds__(CGRT_BLOCK) void k_trace_batch(SceneDev S, const fl
         const F3 o = f3(r[0], r[1], r[2]), d = f3(r[3], r[4], r[5]);
         float t = r[6];
         uint32_t hit_rec = REF_NONE;
-        walk_tree<COUNT>(S, o, d, t, hit_rec, s_ref + threadIdx.x, s_t + threadIdx.x, cnt);
+        walk_tree<COUNT>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
         finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
     }
     if (COUNT) flush_counters(cnt, active, counters);

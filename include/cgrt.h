@@ -86,6 +86,14 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
                       uint32_t nspheres, int device, CgrtScene** out);
 void cgrt_scene_destroy(CgrtScene* scene);
 
+/* In-leaf accelerator (no counterpart upstream; DESIGN.md "In-leaf accelerator").  The reference scans
+ * a leaf's triangles linearly (bvh.cpp:535-553, ~390 per leaf at 800 K triangles).  By default every
+ * scene also gets, per reference leaf, a small BVH that lets the kernel skip triangles the ray cannot
+ * hit; results are identical with it on or off (that is tested), only the work differs.  Process-wide,
+ * applies to scenes created afterwards.  sub_leaf_tris: triangles per accelerator leaf, 0 = default (4). */
+int cgrt_set_leaf_accel(int enabled, int sub_leaf_tris);
+int cgrt_num_subnodes(const CgrtScene* scene);
+
 /* BoundingVolumeHierarchy::numLevels() (bvh.cpp:214-224). */
 int cgrt_num_levels(const CgrtScene* scene);
 /* Tree introspection for builder-parity tests (the reference keeps std::vector<Node>, bvh.h:6-13).

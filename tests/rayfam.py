@@ -100,6 +100,17 @@ def families(sd, node_boxes, primary, rng=None, n_random=1500):
         dz[1::3, 1] = 0.0
         fam["inside_boxes"] = _mk(ctr, dz)
 
+    # extreme magnitudes: far-away origins aimed at the scene, tiny / huge direction scales, mixed
+    # (exercise the "irregular ray" fallback of the in-leaf accelerator and overflow/underflow paths)
+    m = 240
+    tgt2 = rng.uniform(-0.5, 0.5, (m, 3))
+    dirs = _norm(rng.normal(size=(m, 3))).astype(np.float64)
+    dist = np.repeat([1e3, 1e6, 1e9, 1e13, 3e-3, 30.0], m // 6)[:, None]
+    oo = (tgt2 - dirs * dist).astype(np.float32)
+    dd = dirs.astype(np.float32)
+    scl = np.tile(np.float32([1.0, 1e-15, 1e15, 1e-30, 1e30, 1e-38]), m // 6)[:, None]
+    fam["extreme"] = _mk(oo, (dd * scl).astype(np.float32))
+
     fam["f4_cube"] = _mk(np.broadcast_to(np.float32(F4_ORIGIN), (3, 3)), np.float32(F4_DIRS))
     return fam
 

@@ -240,19 +240,90 @@ def test_trace_primary_tiles_partition_the_image(pkg, scene_data):
     assert part[inside].tobytes() == full[inside].tobytes()
 
 
-def test_counters_match_oracle_replay(pkg, orc, scene_data):
-    """cgrt_count_* (instrumented launch) == the oracle's count of the same traversal."""
-    sd = scene_data("monkey")
+def test_counters_match_oracle_replay(pkg, orc):
+    """cgrt_count_* (instrumented launch) == the oracle's count of the same traversal: the reference tree is
+    walked node for node like the reference does; with the in-leaf accelerator off the triangle tests match
+    too, with it on they can only go down."""
+    sd = pkg.scenes.make_dragon(20_000)
     W = H = 200
     cam = pkg.scenes.default_camera(W, H)
-    sc, o = pkg.Scene(sd), orc.OracleScene(sd)
+    o = orc.OracleScene(sd)
     _, cnt = o.intersect(orc.generate_rays(cam, W, H), counters=True)
-    got = sc.count_primary(cam, W, H)
-    assert got["rays"] == W * H
+    try:
+        pkg.set_leaf_accel(False)
+        lin = pkg.Scene(sd)
+    finally:
+        pkg.set_leaf_accel(True)
+    acc = pkg.Scene(sd)
+    assert lin.num_subnodes() == 0 and acc.num_subnodes() > 0
+    got = lin.count_primary(cam, W, H)
+    assert got["rays"] == W * H and got["sub_visits"] == 0
     assert got["inner_visits"] == cnt["inner_visits"] and got["leaf_visits"] == cnt["leaf_visits"]
     assert got["tri_tests"] == cnt["tri_tests"]
-    got2 = sc.count_batch(sc.generate_rays(cam, W, H))
+    got2 = lin.count_batch(lin.generate_rays(cam, W, H))
     assert {k: got2[k] for k in ("inner_visits", "leaf_visits", "tri_tests")} == {k: got[k] for k in ("inner_visits", "leaf_visits", "tri_tests")}
+    ga = acc.count_primary(cam, W, H)
+    assert ga["inner_visits"] == cnt["inner_visits"] and ga["leaf_visits"] == cnt["leaf_visits"]
+    assert 0 < ga["tri_tests"] < 0.5 * cnt["tri_tests"] and ga["sub_visits"] > 0
+
+
+@pytest.mark.parametrize("sub_leaf", [1, 4, 16])
+def test_leaf_accelerator_does_not_change_results(pkg, orc, sub_leaf):
+    """Same bits with the in-leaf accelerator on (any sub-leaf size) and off, on every ray family -- incl.
+    irregular rays (far origins, tiny/huge directions) that take the test-everything path inside leaves."""
+    sd = pkg.scenes.make_dragon(30_000)
+    o = orc.OracleScene(sd)
+    _, boxes = o.nodes()
+    W = H = 64
+    fam = rayfam.families(sd, boxes, orc.generate_rays(pkg.scenes.default_camera(W, H), W, H), rng=np.random.RandomState(5),
+                          n_random=3000)
+    rays = rayfam.concat(fam)
+    ref = o.intersect(rays)
+    try:
+        pkg.set_leaf_accel(False)
+        lin = pkg.Scene(sd)
+        pkg.set_leaf_accel(True, sub_leaf)
+        acc = pkg.Scene(sd)
+    finally:
+        pkg.set_leaf_accel(True)
+    h0, n0 = lin.intersect(_rays(pkg, rays))
+    h1, n1 = acc.intersect(_rays(pkg, rays))
+    _assert_hits_equal(h0, n0, ref, "linear leaves")
+    _assert_hits_equal(h1, n1, ref, f"accelerated leaves (sub_leaf={sub_leaf})")
+    assert ref["hit"].sum() > 0.3 * len(rays)
+
+
+def test_leaf_accelerator_ties_and_on_plane(pkg, orc):
+    """Coplanar, overlapping, duplicated triangles in ONE fat leaf: equal-t ties must go to the earliest scan
+    position and origin-on-plane acceptances to the last one, whatever order the accelerator visits them in."""
+    rng = np.random.RandomState(21)
+    n = 6000  # > 2048 leaves x 1 => fat leaves of ~3; use few distinct planes so ties are everywhere
+    planes_z = np.float32([0.0, 0.25, 0.5])
+    rows, tris = [], []
+    base_tris = rng.uniform(-1, 1, (40, 3, 2)).astype(np.float32)
+    for i in range(n):
+        bt = base_tris[rng.randint(0, len(base_tris))]  # heavy duplication
+        z = planes_z[rng.randint(0, 3)]
+        for k in range(3):
+            rows.append([bt[k, 0], bt[k, 1], z, 0, 0, 1])
+        tris.append((3 * i, 3 * i + 1, 3 * i + 2))
+    sd = pkg.scenes.SceneData(pos_nrm=np.float32(rows), tri=np.uint32(tris), tri_mesh=np.zeros(n, np.uint32),
+                              materials=np.ones((1, 8), np.float32))
+    o = orc.OracleScene(sd)
+    m = 20000
+    oo = np.concatenate([rng.uniform(-1, 1, (m, 2)), rng.choice([-1.0, 0.0, 0.25, 0.5, 0.125, 2.0], (m, 1))], 1).astype(np.float32)
+    dd = np.zeros((m, 3), np.float32)
+    dd[:, 2] = rng.choice([1.0, -1.0], m)
+    dd[m // 2:, 0:2] = rng.uniform(-0.3, 0.3, (m - m // 2, 2))
+    rays = np.zeros((m, 7), np.float32)
+    rays[:, 0:3], rays[:, 3:6], rays[:, 6] = oo, dd, FMAX
+    rays[::9, 6] = rng.choice([0.0, 0.1, 0.25, 1.0, -3.0], len(rays[::9]))
+    ref = o.intersect(rays)
+    sc = pkg.Scene(sd)
+    assert sc.num_subnodes() > 0
+    hits, normals = sc.intersect(_rays(pkg, rays))
+    _assert_hits_equal(hits, normals, ref, "ties/on-plane")
+    assert (ref["t"][ref["hit"] == 1] == 0).sum() > 500  # origin-on-plane acceptances happened
 
 
 # ---------------------------------------------------------------------------------------------------
