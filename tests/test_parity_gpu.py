@@ -297,7 +297,7 @@ def test_leaf_accelerator_ties_and_on_plane(pkg, orc):
     """Coplanar, overlapping, duplicated triangles in ONE fat leaf: equal-t ties must go to the earliest scan
     position and origin-on-plane acceptances to the last one, whatever order the accelerator visits them in."""
     rng = np.random.RandomState(21)
-    n = 6000  # > 2048 leaves x 1 => fat leaves of ~3; use few distinct planes so ties are everywhere
+    n = 40000  # 2048 leaves of ~20 triangles; few distinct planes and shapes so that ties are everywhere
     planes_z = np.float32([0.0, 0.25, 0.5])
     rows, tris = [], []
     base_tris = rng.uniform(-1, 1, (40, 3, 2)).astype(np.float32)
