@@ -52,6 +52,20 @@ def cpu_baseline(pkg, sd, cam, W, H, budget_s=15.0):
     }
 
 
+def read_traffic(workload: str):
+    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic_latest.json, written by
+    tools/profile_round.sh on the GPU box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+    correction applied as MI355X_MICROARCH.md prescribes).  None when no pass matches this workload."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    try:
+        tj = json.load(open(tpath))
+        if tj.get("workload") == workload:
+            return tj.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +103,8 @@ def main():
     W, H = tiling.frame_for_world(world)
     if args.width and args.height:
         W, H = args.width, args.height
+    if os.environ.get("CGRT_SUB_LEAF"):  # experiment knob: triangles per in-leaf accelerator run
+        pkg.set_leaf_accel(True, int(os.environ["CGRT_SUB_LEAF"]))
     sd = pkg.scenes.make_dragon(args.tris)
     cam = pkg.scenes.default_camera(W, H)
     t0 = time.time()
@@ -134,15 +150,7 @@ def main():
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == f"dragon{sd.ntris}_{W}x{H}":
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = read_traffic(f"dragon{sd.ntris}_{W}x{H}")
         out = {
             "metric": "primary Mrays/sec (BVH traversal + ray-triangle, dragon stand-in @1920x1080 per GPU)",
             "value": round(total_rays / (wall_max / args.steps) / 1e6, 3),

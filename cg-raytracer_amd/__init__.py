@@ -21,7 +21,7 @@ from . import scenes  # noqa: F401  (re-export)
 from .scenes import SceneData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcgrt.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("CGRT_LIB_NAME", "libcgrt.so"))  # CGRT_LIB_NAME: experiment builds
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 NO_PRIM = 0xFFFFFFFF
@@ -85,7 +85,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_count_primary", "cgrt_count_batch", "cgrt_record_sizes",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
 ]  # fmt: skip
@@ -123,6 +123,8 @@ def lib() -> C.CDLL:
     L.cgrt_generate_rays.argtypes = [vp, C.POINTER(Camera)] + [i32] * 6 + [vp]
     L.cgrt_count_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [C.POINTER(Counters)]
     L.cgrt_count_batch.argtypes = [vp, vp, u64, C.POINTER(Counters)]
+    L.cgrt_debug_fastdiv_check.argtypes = [i32, vp, vp, u64, vp, vp]
+    L.cgrt_debug_wave_times.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u64]
     L.cgrt_record_sizes.argtypes = [C.POINTER(u32)] * 4
     L.cgrt_record_sizes.restype = None
     L.cgrt_ray_triangle_batch.argtypes = [i32, vp, vp, u64, vp, vp, vp]
@@ -278,6 +280,15 @@ class Scene:
         _check(lib().cgrt_count_primary(self._h, C.byref(c), W, H, x0, y0, x1, y1, rank, nranks, C.byref(out)))
         return out.as_dict()
 
+    def debug_wave_times(self, cam, W, H) -> np.ndarray:
+        """(ntiles, 16) u64 per wave, see cgrt_debug_wave_times in include/cgrt.h (diagnostic launch)."""
+        nst = ((W + 63) // 64) * ((H + 63) // 64)
+        nt = 4 * 16 * 8 * ((nst + 7) // 8)
+        out = np.zeros((nt, 16), np.uint64)
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_debug_wave_times(self._h, C.byref(c), W, H, _ptr(out), nt))
+        return out
+
     def count_batch(self, rays: np.ndarray) -> dict:
         rays = np.ascontiguousarray(rays, RAY_DTYPE)
         out = Counters()
@@ -320,6 +331,16 @@ def ray_sphere(sph4, rays, device=0):
     t, hit, nrm = np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros((n, 3), np.float32)
     _check(lib().cgrt_ray_sphere_batch(device, _ptr(sph4), _ptr(rays), n, _ptr(t), _ptr(hit), _ptr(nrm)))
     return t, hit, nrm
+
+
+def fastdiv_check(a, d, device=0):
+    """(mismatch count, first_bad[a, d, got, expected]) of the kernels' exact fast division vs IEEE a / d."""
+    a = np.ascontiguousarray(a, np.float32).reshape(-1)
+    d = np.ascontiguousarray(d, np.float32).reshape(-1)
+    mm = np.zeros(1, np.uint64)
+    bad = np.zeros(4, np.float32)
+    _check(lib().cgrt_debug_fastdiv_check(device, _ptr(a), _ptr(d), len(a), _ptr(mm), _ptr(bad)))
+    return int(mm[0]), bad
 
 
 def triangle_plane(tri9, device=0):

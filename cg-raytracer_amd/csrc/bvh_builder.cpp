@@ -179,26 +179,22 @@ struct SubBuilder {
         nodes.push_back(SubNode());
         const uint32_t m = split(b, e, depth_left);
         const Box6 lb = range_box(b, m), rb = range_box(m, e);
-        uint32_t ref[2], cnt[2];
+        uint32_t ref[2];
         const uint32_t rb_[2] = {b, m}, re_[2] = {m, e};
         for (int c = 0; c < 2; c++) {
             const uint32_t cn = re_[c] - rb_[c];
             // a child becomes a run of records when it is small enough or no depth is left
-            if (cn <= (uint32_t)leaf_tris || depth_left - 1 <= 0) {
-                ref[c] = REF_LEAF | (base + rb_[c]);
-                cnt[c] = cn;
-            } else {
+            if (cn <= (uint32_t)leaf_tris || depth_left - 1 <= 0)
+                ref[c] = REF_LEAF | ((cn - 1) << 26) | (base + rb_[c]);
+            else
                 ref[c] = build(base, rb_[c], re_[c], depth_left - 1);
-                cnt[c] = 0;
-            }
         }
         SubNode& N = nodes[me];
         std::memcpy(N.box0, &lb, 24);
         std::memcpy(N.box1, &rb, 24);
         N.ref0 = ref[0];
         N.ref1 = ref[1];
-        N.cnt0 = cnt[0];
-        N.cnt1 = cnt[1];
+        N.pad[0] = N.pad[1] = 0;
         return me;
     }
 
@@ -207,6 +203,7 @@ struct SubBuilder {
         if (n <= (uint32_t)leaf_tris) return;  // small leaf: all candidates are tested
         int lt = leaf_tris;
         while (capacity(SUB_MAX_DEPTH, lt) < n) lt *= 2;  // giant leaf: coarser sub-leaves, same depth bound
+        if ((uint32_t)lt > SUB_RUN_MAX || (uint64_t)L.first + n > SUB_MAX_RECORDS) return;  // beyond the encoding: scanned linearly
         const int saved = leaf_tris;
         leaf_tris = lt;
         tb.resize(n);
@@ -423,6 +420,21 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
             if (c > out.scene_absmax) out.scene_absmax = c;  // NaN coordinates never raise it
         }
     if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
+    // one 64-byte record array on the device: [packets | subnodes | tris]; make sub/tri references global
+    out.sub_base = (uint32_t)out.packets.size();
+    out.tri_base = out.sub_base + (uint32_t)out.subnodes.size();
+    if ((uint64_t)out.tri_base + out.tris.size() > SUB_MAX_RECORDS) {
+        // run references carry 26 index bits: beyond that the accelerator is dropped (linear leaves)
+        out.subnodes.clear();
+        for (LeafRec& L : out.leaves) L.sub_root = REF_NONE;
+        out.tri_base = out.sub_base;
+    }
+    for (LeafRec& L : out.leaves) {
+        L.first += out.tri_base;
+        if (L.sub_root != REF_NONE) L.sub_root += out.sub_base;
+    }
+    for (SubNode& N : out.subnodes)
+        for (uint32_t* r : {&N.ref0, &N.ref1}) *r += (*r & REF_LEAF) ? out.tri_base : out.sub_base;
     out.root_box = out.nodes[0].box;
     out.root_ref = ref_of(0);
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

@@ -40,6 +40,9 @@ struct BuiltBvh {
     std::vector<TriNormals> tri_normals;
     std::vector<SubNode> subnodes;       // in-leaf accelerators of all leaves (empty when disabled)
     float scene_absmax = 0;              // largest |vertex coordinate|
+    // The three kinds of 64-byte records live in ONE device array [packets | subnodes | tris]; after
+    // globalize_refs() every reference to a subnode or triangle record is an index into that array.
+    uint32_t sub_base = 0, tri_base = 0;
     std::vector<SphereRecord> spheres;
     Box6 root_box{};
     uint32_t root_ref = REF_NONE;

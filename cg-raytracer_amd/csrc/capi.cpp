@@ -98,10 +98,13 @@ bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nran
     F.y1 = y1;
     F.tiles_x = (x1 - x0 + 7) / 8;
     F.tiles_y = (y1 - y0 + 7) / 8;
+    F.st_x = (F.tiles_x + ST_TILES - 1) / ST_TILES;
+    F.st_y = (F.tiles_y + ST_TILES - 1) / ST_TILES;
     F.rank = rank;
     F.nranks = nranks;
-    const uint64_t nt = (uint64_t)F.tiles_x * (uint64_t)F.tiles_y;
-    F.ntiles_rank = (uint32_t)((nt + (uint64_t)nranks - 1 - (uint64_t)rank) / (uint64_t)nranks);
+    const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
+    F.nst_rank = (uint32_t)((nst + (uint64_t)nranks - 1 - (uint64_t)rank) / (uint64_t)nranks);
+    F.nblocks = ((F.nst_rank + 7u) / 8u) * 8u * 16u;
     return true;
 }
 
@@ -112,18 +115,16 @@ struct CgrtScene {
     BuiltBvh bvh;
     uint32_t ntris = 0;
     SceneDev dev{};
-    void* d_packets = nullptr;
+    void* d_records = nullptr;  // [packets | subnodes | tris], 64 B each
     void* d_leaves = nullptr;
-    void* d_tris = nullptr;
     void* d_tri_normals = nullptr;
     void* d_spheres = nullptr;
-    void* d_subnodes = nullptr;
     unsigned long long* d_counters = nullptr;
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_packets, d_leaves, d_tris, d_tri_normals, d_spheres, d_subnodes, (void*)d_counters})
+        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, (void*)d_counters})
             if (p) (void)hipFree(p);
     }
 };
@@ -186,9 +187,25 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
             return CGRT_OK;
         }
         uint64_t total = 0;
-        if ((rc = upload(s->bvh.packets, &s->d_packets, total)) || (rc = upload(s->bvh.leaves, &s->d_leaves, total)) ||
-            (rc = upload(s->bvh.tris, &s->d_tris, total)) || (rc = upload(s->bvh.tri_normals, &s->d_tri_normals, total)) ||
-            (rc = upload(s->bvh.spheres, &s->d_spheres, total)) || (rc = upload(s->bvh.subnodes, &s->d_subnodes, total))) {
+        {
+            static_assert(sizeof(NodePacket) == 64 && sizeof(SubNode) == 64 && sizeof(TriRecord) == 64, "record size");
+            const BuiltBvh& B = s->bvh;
+            const size_t nrec = B.packets.size() + B.subnodes.size() + B.tris.size();
+            hipError_t e = hipMalloc(&s->d_records, nrec ? nrec * 64 : 64);
+            char* base = static_cast<char*>(s->d_records);
+            if (e == hipSuccess && !B.packets.empty()) e = hipMemcpy(base, B.packets.data(), B.packets.size() * 64, hipMemcpyHostToDevice);
+            if (e == hipSuccess && !B.subnodes.empty())
+                e = hipMemcpy(base + (size_t)B.sub_base * 64, B.subnodes.data(), B.subnodes.size() * 64, hipMemcpyHostToDevice);
+            if (e == hipSuccess && !B.tris.empty())
+                e = hipMemcpy(base + (size_t)B.tri_base * 64, B.tris.data(), B.tris.size() * 64, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                delete s;
+                return hip_fail(e, "uploading the record array");
+            }
+            total += nrec * 64;
+        }
+        if ((rc = upload(s->bvh.leaves, &s->d_leaves, total)) || (rc = upload(s->bvh.tri_normals, &s->d_tri_normals, total)) ||
+            (rc = upload(s->bvh.spheres, &s->d_spheres, total))) {
             delete s;
             return rc;
         }
@@ -199,13 +216,20 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
         }
         s->device_bytes = total;
         SceneDev& D = s->dev;
-        D.packets = static_cast<const NodePacket*>(s->d_packets);
+        D.packets = static_cast<const NodePacket*>(s->d_records);
+        D.subnodes = static_cast<const SubNode*>(s->d_records);
+        D.tris = static_cast<const TriRecord*>(s->d_records);
+        D.tri_base = s->bvh.tri_base;
         D.leaves = static_cast<const LeafRec*>(s->d_leaves);
-        D.tris = static_cast<const TriRecord*>(s->d_tris);
         D.tri_normals = static_cast<const TriNormals*>(s->d_tri_normals);
         D.spheres = static_cast<const SphereRecord*>(s->d_spheres);
-        D.subnodes = static_cast<const SubNode*>(s->d_subnodes);
         D.scene_eps = s->bvh.scene_absmax * 1.52587890625e-05f;  // 2^-16
+        D.fast_boxes = 1;
+        for (const TopoNode& n : s->bvh.nodes)
+            for (int k = 0; k < 6; k++) {
+                const float c = std::fabs(k < 3 ? n.box.lo[k] : n.box.hi[k - 3]);
+                if (!(c == 0.0f || (c >= 9.094947017729282e-13f && c <= 1099511627776.0f))) D.fast_boxes = 0;
+            }
         D.root_box = s->bvh.root_box;
         D.root_ref = s->bvh.root_ref;
         D.ntris = ntris;
@@ -374,6 +398,25 @@ int cgrt_count_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     return read_counters(s, out);
 }
 
+int cgrt_debug_wave_times(CgrtScene* s, const CgrtCamera* cam, int W, int H, uint64_t* out, uint64_t cap_waves) {
+    if (!s || !cam || !out) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    FrameDev F;
+    if (!make_frame(W, H, 0, 0, W, H, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame");
+    const size_t nwaves = (size_t)F.nblocks * 4;
+    if (cap_waves < nwaves) return fail(CGRT_E_ARG, "output too small");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dh, ds;
+    HIP_TRY(dh.alloc((size_t)W * (size_t)H * sizeof(CgrtHit)));
+    HIP_TRY(ds.alloc(nwaves * 128));
+    HIP_TRY(hipMemset(ds.p, 0, nwaves * 128));
+    for (int rep = 0; rep < 3; rep++)  // warm caches, keep the last
+        HIP_TRY(launch_trace_primary_stamped(s->dev, make_camera(*cam), F, dh.as<CgrtHitDev>(), ds.as<unsigned long long>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, ds.p, nwaves * 128, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
 int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters* out) {
     if (!s || !out || (n && !rays)) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
@@ -471,6 +514,25 @@ int cgrt_ray_sphere_batch(int device, const float* sphere, const CgrtRay* rays, 
     HIP_TRY(hipMemcpy(t_out, t.p, n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(hit, h.p, n, hipMemcpyDeviceToHost));
     if (normals) HIP_TRY(hipMemcpy(normals, nn.p, n * 12, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_debug_fastdiv_check(int device, const float* a, const float* d, uint64_t n, uint64_t* mismatches, float* first_bad) {
+    if (n && (!a || !d || !mismatches || !first_bad)) return fail(CGRT_E_ARG, "NULL argument");
+    PRIM_PROLOGUE(device)
+    DevBuf da, dd, dm, db;
+    HIP_TRY(da.alloc(n * 4));
+    HIP_TRY(dd.alloc(n * 4));
+    HIP_TRY(dm.alloc(8));
+    HIP_TRY(db.alloc(16));
+    HIP_TRY(hipMemcpy(da.p, a, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dd.p, d, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dm.p, 0, 8));
+    HIP_TRY(hipMemset(db.p, 0, 16));
+    HIP_TRY(launch_fastdiv_check(da.as<float>(), dd.as<float>(), n, dm.as<unsigned long long>(), db.as<float>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(mismatches, dm.p, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first_bad, db.p, 16, hipMemcpyDeviceToHost));
     return CGRT_OK;
 }
 

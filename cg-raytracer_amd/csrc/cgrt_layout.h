@@ -34,16 +34,18 @@ static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
 
 // One node of a leaf's in-leaf accelerator (a binary BVH over the triangles of ONE reference leaf,
 // DESIGN.md "In-leaf accelerator"), both child boxes inline (64 B).  A child is another SubNode
-// (ref = index) or a run of TriRecords (ref = REF_LEAF | first record, cnt = number of records).
+// (ref = index) or a run of 1..32 TriRecords (ref = REF_LEAF | (count - 1) << 26 | first record).
 struct alignas(16) SubNode {
     float box0[6];
     float box1[6];
     uint32_t ref0, ref1;
-    uint32_t cnt0, cnt1;
+    uint32_t pad[2];
 };
+static const uint32_t SUB_RUN_MAX = 32;            // records per run
+static const uint32_t SUB_MAX_RECORDS = 1u << 26;  // run references address records with 26 bits
 static_assert(sizeof(SubNode) == 64, "SubNode must be 64 B");
-static const int SUB_MAX_DEPTH = 12;   // per-ray sub-stack never exceeds this many entries
-static const int SUB_LEAF_TRIS = 4;    // target triangles per sub-leaf
+static const int SUB_MAX_DEPTH = 8;    // per-ray sub-stack never exceeds this many entries
+static const int SUB_LEAF_TRIS = 3;    // target triangles per sub-leaf (1..4 measure within 2 %; 3 was best on the dragon frame)
 
 // One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent
 // trianglePlane (ray_tracing.cpp:74-82) evaluated once on the host with the reference's arithmetic.
@@ -76,14 +78,19 @@ struct Box6 {
 
 // Everything a kernel needs, passed by value.
 struct SceneDev {
+    // ONE device array of 64-byte records, [NodePackets | SubNodes | TriRecords]; the three typed views
+    // below all point at its start and every reference is an index into it (the traversal loop has one
+    // load site whatever kind of record a lane needs next).
     const NodePacket* packets;
-    const LeafRec* leaves;
-    const TriRecord* tris;
-    const TriNormals* tri_normals;  // indexed like tris (leaf order)
-    const SphereRecord* spheres;
     const SubNode* subnodes;
+    const TriRecord* tris;
+    uint32_t tri_base;              // index of the first TriRecord
+    const LeafRec* leaves;
+    const TriNormals* tri_normals;  // indexed by (record index - tri_base)
+    const SphereRecord* spheres;
     Box6 root_box;
     float scene_eps;    // 2^-16 * largest |coordinate| of the scene: conservative slack of the in-leaf boxes
+    uint32_t fast_boxes;  // every reference box coordinate is 0 or in [2^-40, 2^40]: trace_kernels.hip RayFast
     uint32_t root_ref;  // REF_NONE when the scene has no meshes (bvh.cpp:870)
     uint32_t ntris;
     uint32_t nspheres;
@@ -99,12 +106,21 @@ struct CameraDev {
     float half_w, half_h;
 };
 
+// Frame decomposition.  The rectangle is cut into 8x8-pixel tiles (one wave each) grouped into
+// super-tiles of 8x8 tiles (64x64 pixels).  Super-tile i (row-major) belongs to rank i % nranks, and
+// inside a rank its j-th super-tile is traced by the workgroups with blockIdx % 8 == j % 8, i.e. (with
+// the round-robin workgroup->XCD placement observed on MI355X) by ONE XCD, whose 4 MiB L2 then holds
+// that screen region's nodes and triangles instead of sharing every region with the 7 other L2s.
+// Placement is a speed matter only: results do not depend on it.
 struct FrameDev {
     int W, H;
     int x0, y0, x1, y1;
     int tiles_x, tiles_y;  // 8x8 tiles covering the rectangle
+    int st_x, st_y;        // super-tiles covering the rectangle
     int rank, nranks;
-    uint32_t ntiles_rank;  // tiles this rank owns
+    uint32_t nst_rank;     // super-tiles this rank owns
+    uint32_t nblocks;      // 256-thread workgroups launched: 16 per super-tile, super-tiles padded to 8
 };
+static const int ST_TILES = 8;  // tiles per super-tile side
 
 }  // namespace cgrt

@@ -19,6 +19,8 @@
 // denormals on -- see cgrt_math.h for why.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "cgrt_layout.h"
 #include "cgrt_math.h"
 #include "trace_kernels.h"
@@ -26,13 +28,39 @@
 namespace cgrt {
 
 #define CGRT_BLOCK 256
+// ---- experiment knobs (build variants with -D...; defaults are the shipped configuration) ----
+#ifndef CGRT_SUB_TN
+#define CGRT_SUB_TN 0  // 1: in-leaf stack entries also carry their entry parameter and are culled on pop (measured: no gain,
+                       // +32 B of LDS per lane)
+#endif
+#ifndef CGRT_MIN_WAVES
+#define CGRT_MIN_WAVES 0  // __launch_bounds__ second argument (waves per SIMD) for the trace kernels, 0 = unset
+#endif
+#ifndef CGRT_MAX_WAVES
+#define CGRT_MAX_WAVES 4  // register budget: 4 waves per SIMD = up to 128 VGPRs, no scratch spills (LDS alone would let the
+                          // compiler aim at 5 and spill; measured slower)
+#endif
+#if CGRT_MIN_WAVES > 0
+#define CGRT_LB __launch_bounds__(CGRT_BLOCK, CGRT_MIN_WAVES)
+#else
+#define CGRT_LB __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(1, CGRT_MAX_WAVES)))
+#endif
+#define CGRT_SUB_SLOTS (CGRT_SUB_TN ? 2 : 1)
 // Per-lane LDS stack, in 4-byte slots: a deferred reference child takes 2 slots (ref, tSecond), at most
-// MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 1 slot (node index), at most SUB_MAX_DEPTH.
-#define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + SUB_MAX_DEPTH)
+// MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 2 slots (ref, entry parameter), at most SUB_MAX_DEPTH.
+#define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + CGRT_SUB_SLOTS * SUB_MAX_DEPTH)
 
 struct LaneCounters {
     uint32_t inner = 0, leaf = 0, tri = 0, sub = 0;
+    // wave-level iteration counts (diagnostic): in every executed loop body exactly one active lane adds 1,
+    // so the sum over lanes is the number of times the WAVE ran that body
+    uint32_t w_inner = 0, w_sub = 0, w_tri = 0;
 };
+
+__device__ __forceinline__ bool first_active_lane() {
+    const unsigned long long m = __ballot(1);
+    return (int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63);
+}
 
 __device__ __forceinline__ F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
@@ -95,10 +123,10 @@ struct LeafScan {
     uint32_t onp_rec;
 };
 
-// intersectRayWithTriangle (ray_tracing.cpp:86-114) for record `rec`, reference arithmetic.
-__device__ __forceinline__ void test_record(const SceneDev& S, const uint32_t rec, const F3 o, const F3 d, LeafScan& L) {
-    const float4* q = reinterpret_cast<const float4*>(S.tris + rec);
-    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+// intersectRayWithTriangle (ray_tracing.cpp:86-114) for the record whose four 16-byte quarters are
+// a, b, c, e (already loaded), reference arithmetic.
+__device__ __forceinline__ void test_record(const float4 a, const float4 b, const float4 c, const float4 e, const uint32_t rec,
+                                            const F3 o, const F3 d, LeafScan& L) {
     const F3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.w, b.x, b.y), v2 = f3(b.z, b.w, c.x);
     const F3 n = f3(c.y, c.z, c.w);
     const float D = e.x;
@@ -126,10 +154,37 @@ __device__ __forceinline__ void test_record(const SceneDev& S, const uint32_t re
     L.best_rec = rec;
 }
 
-// intersectLeaf (bvh.cpp:535-553) for one ray.
+// Tests records [first, first + n), two loads in flight (the second record's 64 bytes are requested before
+// the first one is evaluated; a run is 1..32 contiguous records).
+template <bool COUNT>
+__device__ __forceinline__ void test_run(const SceneDev& S, const uint32_t first, const uint32_t n, const F3 o, const F3 d, LeafScan& L,
+                                         LaneCounters& cnt) {
+    if (COUNT) cnt.tri += n;
+    const float4* q = reinterpret_cast<const float4*>(S.tris + first);
+    float4 a0 = q[0], b0 = q[1], c0 = q[2], e0 = q[3];
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t j = (i + 1 < n) ? i + 1 : i;
+        const float4 a1 = q[4 * j], b1 = q[4 * j + 1], c1 = q[4 * j + 2], e1 = q[4 * j + 3];
+        if (COUNT && first_active_lane()) cnt.w_tri++;
+        test_record(a0, b0, c0, e0, first + i, o, d, L);
+        a0 = a1;
+        b0 = b1;
+        c0 = c1;
+        e0 = e1;
+    }
+}
+
+// Run reference inside the in-leaf accelerator: REF_LEAF | (count - 1) << 26 | first record.
+__device__ __forceinline__ uint32_t run_first(const uint32_t r) { return r & 0x03ffffffu; }
+__device__ __forceinline__ uint32_t run_count(const uint32_t r) { return ((r >> 26) & 31u) + 1u; }
+
+// intersectLeaf (bvh.cpp:535-553) for one ray.  "while-while": lanes first step through accelerator nodes
+// until each stands on a run of triangles (or has nothing left), then the runs are tested together.
+// Stack entries are {ref, conservative entry parameter}: an entry is dropped on pop when the scan's
+// running minimum has moved in front of it.
 template <bool COUNT>
 __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, const F3 o, const F3 d, const RayPre& P, float& t,
-                                          uint32_t& hit_rec, uint32_t* __restrict__ stk, int sp, LaneCounters& cnt) {
+                                          uint32_t& hit_rec, uint32_t* __restrict__ stk, const int sp0, LaneCounters& cnt) {
     LeafScan L;
     L.best_t = t;
     L.best_k = -1;
@@ -137,69 +192,59 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
     L.onp_k = -1;
     L.onp_rec = REF_NONE;
     if (LR.sub_root == REF_NONE || !P.regular) {
-        if (COUNT) cnt.tri += LR.count;
-        for (uint32_t i = 0; i < LR.count; i++) test_record(S, LR.first + i, o, d, L);
+        for (uint32_t i = 0; i < LR.count; i += 32) test_run<COUNT>(S, LR.first + i, min(32u, LR.count - i), o, d, L, cnt);
     } else {
-        const int sp0 = sp;
+        int sp = sp0;
         uint32_t cur = LR.sub_root;
         for (;;) {
-            if (COUNT) cnt.sub++;
-            const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
-            const float4 a = q[0], b = q[1], c = q[2];
-            const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
-            float tn0, tf0, tn1, tf1;
-            slab_cons(P, f3(a.x, a.y, a.z), f3(a.w, b.x, b.y), tn0, tf0);
-            slab_cons(P, f3(b.z, b.w, c.x), f3(c.y, c.z, c.w), tn1, tf1);
-            // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
-            // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
-            const float tc = fmaxf(L.best_t, 0.0f);
-            bool h0 = (tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc);
-            bool h1 = (tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc);
-            uint32_t r0 = m.x, r1 = m.y, c0 = m.z, c1 = m.w;
-            if (h0 && h1 && tn1 < tn0) {  // nearer child first
-                const uint32_t tr = r0, tc = c0;
-                r0 = r1;
-                c0 = c1;
-                r1 = tr;
-                c1 = tc;
-                const float tt = tn0;
-                tn0 = tn1;
-                tn1 = tt;
-            } else if (!h0 && h1) {
-                r0 = r1;
-                c0 = c1;
-                tn0 = tn1;
-                h0 = true;
-                h1 = false;
+            // ---- node phase ----
+            while (cur != REF_NONE && !(cur & REF_LEAF)) {
+                if (COUNT) {
+                    cnt.sub++;
+                    if (first_active_lane()) cnt.w_sub++;
+                }
+                const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
+                const float4 a = q[0], b = q[1], c = q[2];
+                const uint2 m = *reinterpret_cast<const uint2*>(q + 3);
+                float tn0, tf0, tn1, tf1;
+                slab_cons(P, f3(a.x, a.y, a.z), f3(a.w, b.x, b.y), tn0, tf0);
+                slab_cons(P, f3(b.z, b.w, c.x), f3(c.y, c.z, c.w), tn1, tf1);
+                // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
+                // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
+                const float tc = fmaxf(L.best_t, 0.0f);
+                const bool h0 = (tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc);
+                const bool h1 = (tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc);
+                const bool swap = h1 && (!h0 || tn1 < tn0);  // child 1 goes first
+                const uint32_t rn = swap ? m.y : m.x, rf = swap ? m.x : m.y;
+                if (h0 && h1) {
+                    stk[sp * CGRT_BLOCK] = rf;
+#if CGRT_SUB_TN
+                    stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(swap ? tn0 : tn1);
+#endif
+                    sp += CGRT_SUB_SLOTS;
+                }
+                cur = (h0 || h1) ? rn : REF_NONE;
             }
-            uint32_t next = REF_NONE;
-            if (h0) {
-                if (r0 & REF_LEAF) {
-                    if (COUNT) cnt.tri += c0;
-                    const uint32_t f = r0 & ~REF_LEAF;
-                    for (uint32_t i = 0; i < c0; i++) test_record(S, f + i, o, d, L);
-                } else {
-                    next = r0;
+            // ---- triangle phase ----
+            if (cur != REF_NONE) test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, L, cnt);
+            // ---- pop ----
+            cur = REF_NONE;
+#if CGRT_SUB_TN
+            while (sp > sp0) {
+                sp -= 2;
+                const float tn = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
+                if (tn <= fmaxf(L.best_t, 0.0f)) {
+                    cur = stk[sp * CGRT_BLOCK];
+                    break;
                 }
             }
-            if (h1 && (tn1 <= fmaxf(L.best_t, 0.0f))) {  // re-checked: the nearer child may have tightened best_t
-                if (r1 & REF_LEAF) {
-                    if (COUNT) cnt.tri += c1;
-                    const uint32_t f = r1 & ~REF_LEAF;
-                    for (uint32_t i = 0; i < c1; i++) test_record(S, f + i, o, d, L);
-                } else if (next == REF_NONE) {
-                    next = r1;
-                } else {
-                    stk[sp * CGRT_BLOCK] = r1;
-                    ++sp;
-                }
+#else
+            if (sp > sp0) {
+                sp -= 1;
+                cur = stk[sp * CGRT_BLOCK];
             }
-            if (next == REF_NONE) {
-                if (sp == sp0) break;
-                --sp;
-                next = stk[sp * CGRT_BLOCK];
-            }
-            cur = next;
+#endif
+            if (cur == REF_NONE) break;
         }
     }
     if (L.onp_k >= 0) {
@@ -211,12 +256,82 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
     }
 }
 
-// Ordered closest-hit walk of the reference tree for one ray.
+// ---------------------------------------------------------------------------------------------
+// Exact fast path for the reference's own box test (ray_tracing.cpp:162-200).
+//
+// That test needs twelve IEEE divisions per inner node, (box.lower - o) / d and (box.upper - o) / d,
+// and their ROUNDED values decide culling and visit order, so they must be the correctly rounded
+// quotients -- an approximate reciprocal is not an option.  hipcc's generic a / b costs ~11 VALU
+// (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup).  For a fixed denominator the quotient can
+// be had in 4: with yh = RN(1/d) (one true division per ray and axis) and yl ~ 1/d - yh,
+//     q0 = RN(a * yh);  q1 = RN(a * yl + q0)          -> q1 is a faithful rounding of a/d (< 1 ulp)
+//     r  = RN(a - d * q1)  (exact, one fma);  q = RN(q1 + r * yh)
+// and Markstein's theorem (IBM J. R&D 34(1), 1990; Muller et al., Handbook of FP Arithmetic, ch. 4:
+// "y correctly rounded reciprocal, q1 faithful  =>  RN(q1 + r*y) = RN(a/d)") makes q the correctly
+// rounded quotient, provided nothing overflows, underflows or is subnormal on the way.  RayFast::fd
+// says that this holds for every box coordinate of the scene and this ray: direction components in
+// [2^-36, 2^36], origin and box coordinates zero or in [2^-40, 2^40] (then every numerator is 0 or in
+// [2^-64, 2^41] and every quotient 0 or in [2^-100, 2^77]).  Under fd no quotient is NaN either, so the
+// reference's `a < b ? a : b` ladders equal min/max up to the sign of a zero, which no comparison sees.
+// Rays outside that envelope (a zero direction component is enough) take the generic path, same bits.
+// tests/test_parity_gpu.py::test_fast_division_is_ieee hammers the 4-op form against a / d on the device.
+struct RayFast {
+    F3 yh, yl;
+    bool fd;
+};
+
+__device__ __forceinline__ float fdiv4(const float a, const float d, const float yh, const float yl) {
+    const float q0 = a * yh;
+    const float q1 = __builtin_fmaf(a, yl, q0);
+    const float r = __builtin_fmaf(-d, q1, a);
+    return __builtin_fmaf(r, yh, q1);
+}
+
+__device__ __forceinline__ bool in_fast_range(const float x, const float lo, const float hi) {
+    const float a = fabsf(x);
+    return (a >= lo) && (a <= hi);  // false for NaN
+}
+
+__device__ __forceinline__ RayFast make_rayfast(const SceneDev& S, const F3 o, const F3 d) {
+    RayFast R;
+    const float dlo = 1.4551915228366852e-11f, dhi = 68719476736.0f;          // 2^-36, 2^36
+    const float clo = 9.094947017729282e-13f, chi = 1099511627776.0f;          // 2^-40, 2^40
+    const bool dok = in_fast_range(d.x, dlo, dhi) && in_fast_range(d.y, dlo, dhi) && in_fast_range(d.z, dlo, dhi);
+    const bool ook = (o.x == 0.0f || in_fast_range(o.x, clo, chi)) && (o.y == 0.0f || in_fast_range(o.y, clo, chi)) &&
+                     (o.z == 0.0f || in_fast_range(o.z, clo, chi));
+    R.fd = dok && ook && (S.fast_boxes != 0);
+    const float dx = R.fd ? d.x : 1.0f, dy = R.fd ? d.y : 1.0f, dz = R.fd ? d.z : 1.0f;
+    R.yh = f3(1.0f / dx, 1.0f / dy, 1.0f / dz);  // true divisions: RN(1/d)
+    R.yl = f3(__builtin_fmaf(-dx, R.yh.x, 1.0f) * R.yh.x, __builtin_fmaf(-dy, R.yh.y, 1.0f) * R.yh.y,
+              __builtin_fmaf(-dz, R.yh.z, 1.0f) * R.yh.z);
+    return R;
+}
+
+// ray_box + starts_in_box for one child box under RayFast::fd.  `inside` is bvh.cpp:647-661
+// (lo < o  <=>  lo - o < 0 exactly, denormals being preserved).
+__device__ __forceinline__ bool ray_box_fast(const F3 lo, const F3 hi, const F3 o, const F3 d, const RayFast& R, const float t,
+                                             float& tbox, bool& inside) {
+    const float ax0 = lo.x - o.x, ay0 = lo.y - o.y, az0 = lo.z - o.z;
+    const float ax1 = hi.x - o.x, ay1 = hi.y - o.y, az1 = hi.z - o.z;
+    const float x0 = fdiv4(ax0, d.x, R.yh.x, R.yl.x), x1 = fdiv4(ax1, d.x, R.yh.x, R.yl.x);
+    const float y0 = fdiv4(ay0, d.y, R.yh.y, R.yl.y), y1 = fdiv4(ay1, d.y, R.yh.y, R.yl.y);
+    const float z0 = fdiv4(az0, d.z, R.yh.z, R.yl.z), z1 = fdiv4(az1, d.z, R.yh.z, R.yl.z);
+    const float tIn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float tOut = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    inside = (fmaxf(fmaxf(ax0, ay0), az0) < 0.0f) && (fminf(fminf(ax1, ay1), az1) > 0.0f);
+    const float cur = (tIn < 0.0f) ? tOut : tIn;
+    tbox = cur;
+    return !((tIn > tOut) || (tOut < 0.0f)) && !(cur >= t);
+}
+
+// Ordered closest-hit walk of the reference tree for one ray ("while-while": every lane first advances
+// through inner nodes until it stands on a leaf or has nothing left, then the leaf lanes scan together;
+// a lane never waits on another lane's leaf scan to take an inner step and vice versa).
 //   t        in/out ray.t
 //   hit_rec  index of the last accepted triangle's TriRecord (REF_NONE if none)
 template <bool COUNT>
 __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
-                                          uint32_t* __restrict__ stk, LaneCounters& cnt) {
+                                             uint32_t* __restrict__ stk, LaneCounters& cnt) {
     uint32_t cur = REF_NONE;
     if (S.root_ref != REF_NONE) {
         // intersectDataStructure, bvh.cpp:831-844 (the box test's write to ray.t is undone there)
@@ -227,80 +342,98 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F
     }
     if (cur == REF_NONE) return;
     const RayPre P = make_raypre(S, o, d, t);
+    const RayFast R = make_rayfast(S, o, d);
     int sp = 0;
     for (;;) {
-        if (cur == REF_NONE) {
-            bool found = false;
-            while (sp > 0) {
-                sp -= 2;
-                const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
-                const uint32_t r = stk[sp * CGRT_BLOCK];
-                if (!(t < ts)) {  // bvh.cpp:582: skip the deferred child iff ray.t < tSecond
-                    cur = r;
-                    found = true;
+        // ---- topology phase: intersectNonLeaf steps until a leaf is reached ----
+        bool done = false;
+        for (;;) {
+            if (cur == REF_NONE) {
+                bool found = false;
+                while (sp > 0) {
+                    sp -= 2;
+                    const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
+                    const uint32_t r = stk[sp * CGRT_BLOCK];
+                    if (!(t < ts)) {  // bvh.cpp:582: skip the deferred child iff ray.t < tSecond
+                        cur = r;
+                        found = true;
+                        break;
+                    }
+                }
+                if (!found) {
+                    done = true;
                     break;
                 }
             }
-            if (!found) break;
-        }
-        if (cur & REF_LEAF) {
-            if (COUNT) cnt.leaf++;
-            scan_leaf<COUNT>(S, S.leaves[cur & ~REF_LEAF], o, d, P, t, hit_rec, stk, sp, cnt);
-            cur = REF_NONE;
-            continue;
-        }
-        // intersectNonLeaf, bvh.cpp:715-736
-        if (COUNT) cnt.inner++;
-        const float4* q = reinterpret_cast<const float4*>(S.packets + cur);
-        const float4 a = q[0], b = q[1], c = q[2];
-        const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
-        const F3 llo = f3(a.x, a.y, a.z), lhi = f3(a.w, b.x, b.y);
-        const F3 rlo = f3(b.z, b.w, c.x), rhi = f3(c.y, c.z, c.w);
-        float tL = -1.0f, tR = -1.0f, tb;
-        if (ray_box(llo, lhi, o, d, t, tb)) tL = tb;
-        if (ray_box(rlo, rhi, o, d, t, tb)) tR = tb;
-        const bool inL = starts_in_box(o, llo, lhi), inR = starts_in_box(o, rlo, rhi);
-        uint32_t first = REF_NONE, second = REF_NONE;
-        float tsec = 0.0f;
-        if (inL && inR) {  // intersectDeeper :685-688, left then right, no culling
-            first = m.x;
-            second = m.y;
-            tsec = -__builtin_inff();
-        } else if (inL) {  // :689-692
-            first = m.x;
-            if (!(tR < 0)) {
-                second = m.y;
-                tsec = tR;
+            if (cur & REF_LEAF) break;
+            // intersectNonLeaf, bvh.cpp:715-736
+            if (COUNT) {
+                cnt.inner++;
+                if (first_active_lane()) cnt.w_inner++;
             }
-        } else if (inR) {  // :693-696
-            first = m.y;
-            if (!(tL < 0)) {
-                second = m.x;
-                tsec = tL;
-            }
-        } else {  // intersectRayThatStartsOutsideBoxes :611-635
-            const bool ml = tL < 0, mr = tR < 0;
-            if (ml && mr) {
-            } else if (ml) {
-                first = m.y;
-            } else if (mr) {
-                first = m.x;
-            } else if (tL < tR) {
-                first = m.x;
-                second = m.y;
-                tsec = tR;
+            const float4* q = reinterpret_cast<const float4*>(S.packets + cur);
+            const float4 a = q[0], b = q[1], c = q[2];
+            const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
+            const F3 llo = f3(a.x, a.y, a.z), lhi = f3(a.w, b.x, b.y);
+            const F3 rlo = f3(b.z, b.w, c.x), rhi = f3(c.y, c.z, c.w);
+            float tL = -1.0f, tR = -1.0f, tb;
+            bool inL, inR;
+            if (R.fd) {
+                if (ray_box_fast(llo, lhi, o, d, R, t, tb, inL)) tL = tb;
+                if (ray_box_fast(rlo, rhi, o, d, R, t, tb, inR)) tR = tb;
             } else {
-                first = m.y;
-                second = m.x;
-                tsec = tL;
+                if (ray_box(llo, lhi, o, d, t, tb)) tL = tb;
+                if (ray_box(rlo, rhi, o, d, t, tb)) tR = tb;
+                inL = starts_in_box(o, llo, lhi);
+                inR = starts_in_box(o, rlo, rhi);
             }
+            uint32_t first = REF_NONE, second = REF_NONE;
+            float tsec = 0.0f;
+            if (inL && inR) {  // intersectDeeper :685-688, left then right, no culling
+                first = m.x;
+                second = m.y;
+                tsec = -__builtin_inff();
+            } else if (inL) {  // :689-692
+                first = m.x;
+                if (!(tR < 0)) {
+                    second = m.y;
+                    tsec = tR;
+                }
+            } else if (inR) {  // :693-696
+                first = m.y;
+                if (!(tL < 0)) {
+                    second = m.x;
+                    tsec = tL;
+                }
+            } else {  // intersectRayThatStartsOutsideBoxes :611-635
+                const bool ml = tL < 0, mr = tR < 0;
+                if (ml && mr) {
+                } else if (ml) {
+                    first = m.y;
+                } else if (mr) {
+                    first = m.x;
+                } else if (tL < tR) {
+                    first = m.x;
+                    second = m.y;
+                    tsec = tR;
+                } else {
+                    first = m.y;
+                    second = m.x;
+                    tsec = tL;
+                }
+            }
+            if (second != REF_NONE) {
+                stk[sp * CGRT_BLOCK] = second;
+                stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
+                sp += 2;
+            }
+            cur = first;
         }
-        if (second != REF_NONE) {
-            stk[sp * CGRT_BLOCK] = second;
-            stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
-            sp += 2;
-        }
-        cur = first;
+        if (done) break;
+        // ---- leaf phase ----
+        if (COUNT) cnt.leaf++;
+        scan_leaf<COUNT>(S, S.leaves[cur & ~REF_LEAF], o, d, P, t, hit_rec, stk, sp, cnt);
+        cur = REF_NONE;
     }
 }
 
@@ -337,7 +470,7 @@ __device__ __forceinline__ void finish_ray(const SceneDev& S, const F3 o, const 
         F3 nn = sn;
         if (!sphere_last) {
             const TriRecord* T = S.tris + hit_rec;
-            const TriNormals* N = S.tri_normals + hit_rec;
+            const TriNormals* N = S.tri_normals + (hit_rec - S.tri_base);
             nn = hit_normal(ld3(T->v0), ld3(T->v1), ld3(T->v2), ld3(T->n), ld3(N->n1), ld3(N->n2), ld3(N->n3), o, d, t);
         }
         out_normal[0] = nn.x;
@@ -370,39 +503,73 @@ __device__ __forceinline__ void primary_ray(const CameraDev& C, int W, int H, in
     o = f3(C.pos[0], C.pos[1], C.pos[2]);
 }
 
-// Wave w of the launch owns tile `rank + nranks * w` of the rectangle's 8x8 tiling; lane -> pixel.
-__device__ __forceinline__ bool tile_pixel(const FrameDev& F, uint32_t wave_global, int lane, int& x, int& y) {
-    if (wave_global >= F.ntiles_rank) return false;
-    const uint32_t tile = (uint32_t)F.rank + (uint32_t)F.nranks * wave_global;
-    const int tx = (int)(tile % (uint32_t)F.tiles_x), ty = (int)(tile / (uint32_t)F.tiles_x);
+// Workgroup -> super-tile -> tile -> pixel (FrameDev in cgrt_layout.h): blockIdx % 8 selects the XCD lane of
+// the rank's super-tile list, 16 consecutive workgroups of that lane cover one 64x64 super-tile, the 4 waves
+// of a workgroup take 4 horizontally adjacent 8x8 tiles.
+__device__ __forceinline__ bool tile_pixel(const FrameDev& F, int lane, int& x, int& y) {
+    const uint32_t b = blockIdx.x, lane8 = b & 7u, j = b >> 3;
+    const uint32_t s = (j >> 4) * 8u + lane8;  // rank-local super-tile
+    if (s >= F.nst_rank) return false;
+    const uint32_t st = (uint32_t)F.rank + (uint32_t)F.nranks * s;
+    const int stx = (int)(st % (uint32_t)F.st_x), sty = (int)(st / (uint32_t)F.st_x);
+    const int idx = (int)(j & 15u) * 4 + (int)(threadIdx.x >> 6);
+    const int tx = stx * ST_TILES + (idx & 7), ty = sty * ST_TILES + (idx >> 3);
     x = F.x0 + tx * 8 + (lane & 7);
     y = F.y0 + ty * 8 + (lane >> 3);
     return x < F.x1 && y < F.y1;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(CGRT_BLOCK) void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits,
+// STAMP (diagnostic build only, never timed): lane 0 of every wave writes {start, end} of s_memtime and
+// s_memrealtime plus its work counters
+// into `counters`, which then is a 16 x nwaves u64 buffer that nothing else reads.
+template <bool COUNT, bool STAMP = false>
+__global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits,
                                                               float* __restrict__ normals, unsigned long long* counters) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = blockIdx.x * (CGRT_BLOCK / 64) + (threadIdx.x >> 6);
+    unsigned long long st0 = 0, rt0 = 0;
+    if (STAMP) {
+        st0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     int x = 0, y = 0;
-    const bool active = tile_pixel(F, wave_global, lane, x, y);
+    const bool active = tile_pixel(F, lane, x, y);
     LaneCounters cnt;
     if (active) {
         F3 o, d;
         primary_ray(C, F.W, F.H, x, y, o, d);
         float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
         uint32_t hit_rec = REF_NONE;
-        walk_tree<COUNT>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
+        walk_tree<COUNT || STAMP>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
         const size_t pix = (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
-    if (COUNT) flush_counters(cnt, active, counters);
+    if (STAMP) {
+        const unsigned long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long nactive = __popcll(__ballot(active));
+        uint32_t v[11] = {cnt.inner, cnt.leaf, cnt.tri, cnt.sub, cnt.w_inner, cnt.w_sub, cnt.w_tri, cnt.inner, cnt.leaf, cnt.tri, cnt.sub};
+        for (int k = 0; k < 11; k++)
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t other = __shfl_down(v[k], off, 64);
+                v[k] = k < 7 ? v[k] + other : (v[k] > other ? v[k] : other);  // sums, then per-lane maxima
+            }
+        if (lane == 0) {
+            unsigned long long* p = counters + 16ull * wave_global;
+            p[0] = st0;
+            p[1] = st1;
+            p[2] = rt0;
+            p[3] = rt1;
+            for (int k = 0; k < 11; k++) p[4 + k] = v[k];
+            p[15] = nactive;
+        }
+    } else if (COUNT) {
+        flush_counters(cnt, active, counters);
+    }
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(CGRT_BLOCK) void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
+__global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                                             unsigned long long* counters) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
@@ -517,6 +684,26 @@ __global__ void k_point_in_triangle(const float* __restrict__ in, unsigned long 
     out[i] = point_in_triangle(ld3(q), ld3(q + 3), ld3(q + 6), ld3(q + 9), ld3(q + 12));
 }
 
+// diagnostic / test kernel: fdiv4 against IEEE a / d, bit for bit (zeros compare equal regardless of sign)
+__global__ void k_fastdiv_check(const float* __restrict__ a, const float* __restrict__ d, unsigned long long n,
+                                unsigned long long* __restrict__ mismatches, float* __restrict__ first_bad) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dd = d[i], aa = a[i];
+    const float yh = 1.0f / dd;
+    const float yl = __builtin_fmaf(-dd, yh, 1.0f) * yh;
+    const float q = fdiv4(aa, dd, yh, yl), ref = aa / dd;
+    const bool same = (__float_as_uint(q) == __float_as_uint(ref)) || (q == 0.0f && ref == 0.0f);
+    if (!same) {
+        if (atomicAdd(mismatches, 1ull) == 0ull) {
+            first_bad[0] = aa;
+            first_bad[1] = dd;
+            first_bad[2] = q;
+            first_bad[3] = ref;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------------------
@@ -524,12 +711,23 @@ static inline unsigned grid_for(unsigned long long n, unsigned block) { return (
 
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
                                 unsigned long long* counters, hipStream_t stream) {
-    if (F.ntiles_rank == 0) return hipSuccess;
-    const unsigned blocks = grid_for(F.ntiles_rank, CGRT_BLOCK / 64);
+    if (F.nblocks == 0) return hipSuccess;
+    const unsigned blocks = F.nblocks;
+    static const unsigned lds_pad = [] {
+        const char* e = getenv("CGRT_EXP_LDS_PAD");  // experiment knob: extra dynamic LDS to cap blocks per CU
+        return e ? (unsigned)atoi(e) : 0u;
+    }();
     if (counters)
-        hipLaunchKernelGGL(k_trace_primary<true>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, hits, normals, counters);
+        hipLaunchKernelGGL(k_trace_primary<true>, dim3(blocks), dim3(CGRT_BLOCK), lds_pad, stream, S, C, F, hits, normals, counters);
     else
-        hipLaunchKernelGGL(k_trace_primary<false>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, hits, normals, counters);
+        hipLaunchKernelGGL(k_trace_primary<false>, dim3(blocks), dim3(CGRT_BLOCK), lds_pad, stream, S, C, F, hits, normals, counters);
+    return hipGetLastError();
+}
+hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits,
+                                        unsigned long long* stamps, hipStream_t stream) {
+    if (F.nblocks == 0) return hipSuccess;
+    const unsigned blocks = F.nblocks;
+    hipLaunchKernelGGL((k_trace_primary<false, true>), dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, hits, nullptr, stamps);
     return hipGetLastError();
 }
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
@@ -546,6 +744,11 @@ hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0
     const unsigned long long n = (unsigned long long)(x1 - x0) * (unsigned long long)(y1 - y0);
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_generate_rays, dim3(grid_for(n, CGRT_BLOCK)), dim3(CGRT_BLOCK), 0, stream, C, W, H, x0, y0, x1, y1, rays);
+    return hipGetLastError();
+}
+hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,
+                                hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fastdiv_check, dim3(grid_for(n, 256)), dim3(256), 0, s, a, d, n, mismatches, first_bad);
     return hipGetLastError();
 }
 hipError_t launch_ray_triangle(const float* tri, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, float* normals,

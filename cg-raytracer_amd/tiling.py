@@ -1,6 +1,6 @@
-"""Image tiling across GPUs: the frame is cut into 8x8-pixel tiles, tile i belongs to
-rank i % nranks (interleaved, so silhouette-heavy regions spread over all ranks), the scene is replicated
-and no data-path collective exists.  Pure host logic shared by bench.py and the world_size-2 gloo tests;
+"""Image tiling across GPUs: the frame is cut into 8x8-pixel tiles (one wave each), grouped
+into 64x64-pixel super-tiles; super-tile i (row-major) belongs to rank i % nranks (interleaved, so
+silhouette-heavy regions spread over all ranks), the scene is replicated and no data-path collective exists.  Pure host logic shared by bench.py and the world_size-2 gloo tests;
 ``owned_mask`` restates what the kernel's tile_pixel() computes."""
 from __future__ import annotations
 
@@ -9,6 +9,7 @@ import math
 import numpy as np
 
 TILE = 8
+SUPER = 64  # super-tile side in pixels (8 x 8 tiles)
 BASE_W, BASE_H = 1920, 1080  # BASELINE.json: dragon.obj @1920x1080
 
 
@@ -29,11 +30,11 @@ def tiles(W: int, H: int, rect=None):
 def owned_mask(W: int, H: int, rank: int, nranks: int, rect=None) -> np.ndarray:
     """(H, W) bool: pixels rank `rank` traces."""
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
-    tx, _ = tiles(W, H, rect)
+    stx = (x1 - x0 + SUPER - 1) // SUPER
     yy, xx = np.mgrid[0:H, 0:W]
     inside = (xx >= x0) & (xx < x1) & (yy >= y0) & (yy < y1)
-    tile = ((yy - y0) // TILE) * tx + (xx - x0) // TILE
-    return inside & (tile % nranks == rank)
+    st = ((yy - y0) // SUPER) * stx + (xx - x0) // SUPER
+    return inside & (st % nranks == rank)
 
 
 def owned_pixels(W: int, H: int, rank: int, nranks: int, rect=None) -> int:

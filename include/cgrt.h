@@ -116,8 +116,9 @@ int cgrt_intersect_batch_device(CgrtScene* scene, const CgrtRay* d_rays, uint64_
 
 /* Primary frame: fuses renderRayTracing's ray generation (main.cpp:691-694 + Trackball::generateRay,
  * trackball.cpp:92-103) with intersect; no rays are uploaded.  Pixel (x, y), 0 <= x < W, 0 <= y < H,
- * result index y*W + x (not y-flipped).  Only pixels inside [x0,x1) x [y0,y1) whose 8x8 tile satisfies
- * tile_index % nranks == rank are traced and written (image tiling across GPUs). */
+ * result index y*W + x (not y-flipped).  The rectangle [x0,x1) x [y0,y1) is cut into 64x64-pixel super-tiles
+ * (row-major from (x0, y0)); only pixels whose super-tile index % nranks == rank are traced and written
+ * (image tiling across GPUs). */
 int cgrt_trace_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,
                        int rank, int nranks, CgrtHit* hits, float* normals);
 int cgrt_trace_primary_device(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1,
@@ -131,6 +132,14 @@ int cgrt_generate_rays(CgrtScene* scene, const CgrtCamera* cam, int W, int H, in
 int cgrt_count_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,
                        int rank, int nranks, CgrtCounters* out);
 int cgrt_count_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, CgrtCounters* out);
+/* Diagnostic (not part of the reference surface): one stamped + instrumented full-frame launch; out holds 16 u64
+ * per 8x8 tile (= wave): s_memtime start, end; s_memrealtime start, end; lane-summed inner/leaf/tri/sub steps;
+ * wave-level iterations of the inner, sub-node and triangle bodies; per-lane maxima of inner/leaf/tri/sub; active
+ * lanes.  One record per launched wave: cap_waves >= 4 * 16 * 8 * ceil(ceil(W/64)*ceil(H/64) / 8). */
+int cgrt_debug_wave_times(CgrtScene* scene, const CgrtCamera* cam, int W, int H, uint64_t* out, uint64_t cap_waves);
+/* Diagnostic: the kernels' 4-operation exact division (trace_kernels.hip fdiv4) against IEEE a[i] / d[i] on the
+ * device; mismatches receives the count, first_bad {a, d, got, expected} of the first one. */
+int cgrt_debug_fastdiv_check(int device, const float* a, const float* d, uint64_t n, uint64_t* mismatches, float* first_bad);
 /* Bytes of one inner-node record / one triangle record / one in-leaf accelerator node / one result. */
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes);
 

@@ -68,7 +68,7 @@ def test_two_ranks_partition_and_timing(W, H):
         assert p.exitcode == 0
     (r0, n0, tot0, ok0, w0), (r1, n1, tot1, ok1, w1) = res
     assert ok0 and ok1 and tot0 == tot1 == W * H and n0 + n1 == W * H
-    assert abs(n0 - n1) <= 0.02 * W * H  # interleaved tiles balance the pixel count
+    assert abs(n0 - n1) <= 0.12 * W * H  # interleaved super-tiles roughly balance the pixel count
     assert w0 == w1 and w0 >= 0.1  # both ranks agree on the max-over-ranks time
 
 
