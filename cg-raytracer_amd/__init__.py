@@ -69,13 +69,18 @@ class Camera(C.Structure):
         return cam
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libcgrt_host.so")
+
+
 def build_native(verbose: bool = False) -> str:
-    """Compile libcgrt.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
-    if verbose or r.returncode:
-        print(r.stdout[-4000:], r.stderr[-4000:])
-    if r.returncode:
-        raise RuntimeError("building libcgrt.so failed")
+    """Compile libcgrt.so for gfx950 in-tree (hipcc cross-compiles without a GPU), then the C++ host mirror of the
+    reference interface (libcgrt_host.so + the headless `render` tool, g++)."""
+    for sub in ("csrc", "host"):
+        r = subprocess.run(["make", "-C", os.path.join(_HERE, sub)], capture_output=True, text=True)
+        if verbose or r.returncode:
+            print(r.stdout[-4000:], r.stderr[-4000:])
+        if r.returncode:
+            raise RuntimeError(f"building {sub} failed")
     return LIB_PATH
 
 
@@ -355,3 +360,58 @@ def point_in_triangle(in15, device=0):
     out = np.zeros(len(in15), np.uint8)
     _check(lib().cgrt_point_in_triangle_batch(device, _ptr(in15), len(in15), _ptr(out)))
     return out
+
+
+# ---- C++ host mirror (cg-raytracer_amd/host): render driver, OBJ loader, BMP writer ----
+_host = None
+
+
+def host_lib() -> C.CDLL:
+    global _host
+    if _host is None:
+        lib()  # libcgrt.so first (dependency)
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+        H = C.CDLL(HOST_LIB_PATH)
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        H.cgrt_host_last_error.restype = C.c_char_p
+        H.cgrt_host_render.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, vp, vp]
+        H.cgrt_host_load_obj.argtypes = [C.c_char_p, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp]
+        H.cgrt_host_write_bmp.argtypes = [C.c_char_p, vp, i32, i32]
+        _host = H
+    return _host
+
+
+def host_render(sd: SceneData, cam, W: int, H: int, max_level: int = 2):
+    """renderRayTracing of the C++ host mirror (wavefront over the GPU path). Returns (rgb[H*W,3], stats dict)."""
+    Hl = host_lib()
+    pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+    tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
+    lights, camv = _f32(sd.point_lights, (-1, 6)), _f32(cam, (9,))
+    rgb = np.zeros((W * H, 3), np.float32)
+    st = np.zeros(5, np.float64)
+    rc = Hl.cgrt_host_render(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(lights), len(lights),
+                             _ptr(camv), W, H, max_level, _ptr(rgb), _ptr(st))
+    if rc:
+        raise RuntimeError("cgrt_host_render: " + Hl.cgrt_host_last_error().decode())
+    return rgb, dict(primary=int(st[0]), shadow=int(st[1]), reflection=int(st[2]), seconds_device=float(st[3]), seconds_total=float(st[4]))
+
+
+def host_load_obj(path: str, normalize: bool = False) -> SceneData:
+    """loadMesh of the C++ host mirror, as flat arrays."""
+    Hl = host_lib()
+    nv, nt, nm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if Hl.cgrt_host_load_obj(path.encode(), int(normalize), C.byref(nv), C.byref(nt), C.byref(nm), None, None, None, None):
+        raise RuntimeError("cgrt_host_load_obj: " + Hl.cgrt_host_last_error().decode())
+    pn = np.zeros((nv.value, 6), np.float32)
+    tri = np.zeros((nt.value, 3), np.uint32)
+    tm = np.zeros(nt.value, np.uint32)
+    mats = np.zeros((nm.value, 8), np.float32)
+    Hl.cgrt_host_load_obj(path.encode(), int(normalize), C.byref(nv), C.byref(nt), C.byref(nm), _ptr(pn), _ptr(tri), _ptr(tm), _ptr(mats))
+    return SceneData(pos_nrm=pn, tri=tri, tri_mesh=tm, materials=mats)
+
+
+def host_write_bmp(path: str, rgb, W: int, H: int) -> None:
+    rgb = _f32(rgb, (W * H, 3))
+    if host_lib().cgrt_host_write_bmp(path.encode(), _ptr(rgb), W, H):
+        raise RuntimeError("cgrt_host_write_bmp: " + host_lib().cgrt_host_last_error().decode())

@@ -1,0 +1,167 @@
+// Wavefront restatement of the reference's render driver (src/main.cpp:61-310, :648-720).  See render.h.
+#include "render.h"
+
+#include <chrono>
+#include <cmath>
+#include <limits>
+
+namespace {
+using cgrt::vec3;
+using Clock = std::chrono::steady_clock;
+
+// main.cpp:84-98
+vec3 diffuseOneLight(const PointLight& light, const vec3& fromPosToLight, const HitInfo& hitInfo) {
+    const float diffuseCos = cgrt::dot(fromPosToLight, hitInfo.normal);
+    if (diffuseCos <= 0) return vec3(0.0f);
+    return light.color * hitInfo.material.kd * diffuseCos;
+}
+// main.cpp:61-82 (pow(float, float) must yield float for `vec3 * pow(...)` to compile upstream: powf)
+vec3 specularOneLight(const Ray& ray, const PointLight& light, const vec3& fromPosToLight, const HitInfo& hitInfo) {
+    const vec3 reflected = cgrt::normalize(cgrt::reflect(ray.direction, hitInfo.normal));
+    const float specularCos = cgrt::dot(reflected, fromPosToLight);
+    if (specularCos <= 0) return vec3(0.0f);
+    return light.color * hitInfo.material.ks * std::pow(specularCos, hitInfo.material.shininess);
+}
+
+struct Path {       // one live ray of the current level
+    uint32_t pixel; // index into the level-0 arrays
+    uint32_t parent;  // index of the item of the previous level that spawned it
+};
+struct LevelItem {  // what the backward pass needs: color = direct + reflectedColor * ks  (main.cpp:262)
+    vec3 direct;
+    vec3 ks;
+    bool hit;
+    int child;  // item of the next level, -1 if none
+    uint32_t parent;
+};
+}  // namespace
+
+RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
+                           int maxLevel) {
+    RenderStats st;
+    const auto t_begin = Clock::now();
+    const size_t npix = (size_t)W * H;
+    const float eps = 0.001;  // main.cpp:110, :255
+    std::vector<Ray> rays(npix);
+    std::vector<HitInfo> his(npix);
+    std::vector<uint8_t> hit(npix, 0);
+    std::vector<uint32_t> parent(npix);
+    for (size_t i = 0; i < npix; i++) parent[i] = (uint32_t)i;
+    std::vector<std::vector<LevelItem>> levels;
+    if (maxLevel >= 1) {  // trace(0): `level >= maxLevel` -> black without tracing (main.cpp:267)
+        auto t0 = Clock::now();
+        bvh.tracePrimary(camera.abi(), W, H, rays.data(), his.data(), hit.data());
+        st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
+        st.primary = npix;
+    }
+    for (int level = 0; level < maxLevel && !rays.empty(); level++) {
+        const size_t n = rays.size();
+        const size_t L = scene.pointLights.size();
+        std::vector<LevelItem> items(n);
+        // ---- shadow rays of every hit x light (pointInShadow, main.cpp:104-135) ----
+        std::vector<Ray> srays;
+        std::vector<uint32_t> sowner;
+        std::vector<float> sdist;
+        srays.reserve(n * L);
+        for (size_t i = 0; i < n; i++) {
+            if (!hit[i]) continue;
+            const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
+            for (size_t l = 0; l < L; l++) {
+                const vec3 fromPosToLight = scene.pointLights[l].position - pointOn;
+                Ray r{pointOn, cgrt::normalize(fromPosToLight), std::numeric_limits<float>::max()};
+                r.origin = r.origin + eps * r.direction;
+                srays.push_back(r);
+                sowner.push_back((uint32_t)i);
+                sdist.push_back(cgrt::length(fromPosToLight));
+            }
+        }
+        std::vector<HitInfo> shi(srays.size());
+        std::vector<uint8_t> shit(srays.size(), 0);
+        {
+            auto t0 = Clock::now();
+            bvh.intersectBatch(srays.data(), shi.data(), shit.data(), srays.size());
+            st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
+            st.shadow += srays.size();
+        }
+        // ---- direct light (shading, main.cpp:219-232) + reflection rays (shade, :241-264) ----
+        std::vector<Ray> nrays;
+        std::vector<uint32_t> nparent;
+        size_t s = 0;
+        for (size_t i = 0; i < n; i++) {
+            LevelItem& it = items[i];
+            it.hit = hit[i] != 0;
+            it.child = -1;
+            it.parent = parent[i];
+            it.direct = vec3(0.0f);
+            it.ks = vec3(0.0f);
+            if (!it.hit) continue;
+            const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
+            vec3 result(0.0f);
+            for (size_t l = 0; l < L; l++, s++) {
+                const PointLight& light = scene.pointLights[l];
+                const vec3 fromPosToLight = cgrt::normalize(light.position - pointOn);
+                const bool inShadow = shit[s] && !(srays[s].t + eps >= sdist[s]);  // :118-130
+                if (inShadow) continue;
+                result += diffuseOneLight(light, fromPosToLight, his[i]);
+                result += specularOneLight(rays[i], light, fromPosToLight, his[i]);
+            }
+            it.direct = result;
+            it.ks = his[i].material.ks;
+            if (his[i].material.ks.z <= 0.01f) continue;  // :246: the comma operator leaves only ks.z tested
+            if (level + 1 >= maxLevel) continue;          // trace(level+1) would return black (:267): color = direct + 0 * ks
+            const vec3 reflected = cgrt::normalize(cgrt::reflect(rays[i].direction, his[i].normal));
+            Ray rr{pointOn, reflected, cgrt::length(rays[i].direction)};  // :254: t = |direction|, not FLT_MAX
+            rr.origin = rr.origin + eps * rr.direction;
+            it.child = (int)nrays.size();
+            nrays.push_back(rr);
+            nparent.push_back((uint32_t)i);
+        }
+        levels.push_back(std::move(items));
+        rays = std::move(nrays);
+        parent = std::move(nparent);
+        his.assign(rays.size(), HitInfo{});
+        hit.assign(rays.size(), 0);
+        if (!rays.empty()) {
+            auto t0 = Clock::now();
+            bvh.intersectBatch(rays.data(), his.data(), hit.data(), rays.size());
+            st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
+            st.reflection += rays.size();
+        }
+    }
+    // ---- backward pass: color = directColor + reflectedColor * ks (main.cpp:262), deepest level first ----
+    std::vector<vec3> below;
+    for (int level = (int)levels.size() - 1; level >= 0; level--) {
+        const std::vector<LevelItem>& items = levels[level];
+        std::vector<vec3> color(items.size());
+        for (size_t i = 0; i < items.size(); i++) {
+            const LevelItem& it = items[i];
+            if (!it.hit)
+                color[i] = vec3(0.0f);  // :293
+            else if (it.ks.z <= 0.01f)
+                color[i] = it.direct;  // :248
+            else
+                color[i] = it.direct + (it.child >= 0 ? below[it.child] : vec3(0.0f)) * it.ks;
+        }
+        below = std::move(color);
+    }
+    for (size_t i = 0; i < npix; i++) {
+        const vec3 c = levels.empty() ? vec3(0.0f) : below[i];
+        rgb[3 * i] = c.x;
+        rgb[3 * i + 1] = c.y;
+        rgb[3 * i + 2] = c.z;
+    }
+    st.seconds_total = std::chrono::duration<double>(Clock::now() - t_begin).count();
+    return st;
+}
+
+RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel) {
+    const int W = screen.width(), H = screen.height();
+    std::vector<float> rgb((size_t)W * H * 3);
+    RenderStats st = renderToBuffer(scene, camera, bvh, W, H, rgb.data(), maxLevel);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float* p = &rgb[3 * ((size_t)y * W + x)];
+            screen.setPixel(x, y, cgrt::vec3(p[0], p[1], p[2]));  // main.cpp:696
+        }
+    return st;
+}

@@ -1,0 +1,51 @@
+// Headless stand-in for the reference's interactive main() (src/main.cpp:722-939): load a scene preset or an OBJ,
+// build the BVH, render with the reference's default camera, write render.bmp, print the timing the reference prints
+// (main.cpp:791-797).
+//   render <data-dir> <triangle|cube|cornell|monkey|dragon|custom|file.obj> [W H [maxLevel [out.bmp]]]
+#include <chrono>
+#include <cstring>
+#include <iostream>
+
+#include "render.h"
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::cerr << "usage: render <data-dir> <scene|file.obj> [W H [maxLevel [out.bmp]]]\n";
+        return 2;
+    }
+    const std::filesystem::path dataDir = argv[1];
+    const std::string what = argv[2];
+    const int W = argc > 4 ? std::atoi(argv[3]) : 800, H = argc > 4 ? std::atoi(argv[4]) : 800;  // windowResolution, main.cpp:29
+    const int maxLevel = argc > 5 ? std::atoi(argv[5]) : 2;
+    const std::string out = argc > 6 ? argv[6] : "render.bmp";
+    try {
+        Scene scene;
+        if (what == "triangle") scene = loadScene(SingleTriangle, dataDir);
+        else if (what == "cube") scene = loadScene(Cube, dataDir);
+        else if (what == "cornell") scene = loadScene(CornellBox, dataDir);
+        else if (what == "monkey") scene = loadScene(Monkey, dataDir);
+        else if (what == "dragon") scene = loadScene(Dragon, dataDir);
+        else if (what == "custom") scene = loadScene(Custom, dataDir);
+        else {
+            auto sub = loadMesh(what, true);
+            scene.meshes = std::move(sub);
+            scene.pointLights.push_back(PointLight{cgrt::vec3(-1, 1, -1), cgrt::vec3(1.0f)});
+        }
+        BoundingVolumeHierarchy bvh{&scene};
+        const float rad = 0.01745329251994329576923690768489f;
+        Trackball camera{50.0f * rad, float(W) / float(H), 3.0f};  // main.cpp:730-731
+        camera.setCamera(cgrt::vec3(0.0f), cgrt::vec3(20.0f * rad, 20.0f * rad, 0.0f), 3.0f);
+        Screen screen{W, H};
+        const auto start = std::chrono::high_resolution_clock::now();
+        const RenderStats st = renderRayTracing(scene, camera, bvh, screen, maxLevel);
+        const auto end = std::chrono::high_resolution_clock::now();
+        std::cout << "Time to render image: " << std::chrono::duration<float, std::milli>(end - start).count() << " milliseconds" << std::endl;
+        std::cout << "BVH levels " << bvh.numLevels() << "; rays: " << st.primary << " primary, " << st.shadow << " shadow, " << st.reflection
+                  << " reflection; device share " << st.seconds_device << " s" << std::endl;
+        screen.writeBitmapToFile(out);
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

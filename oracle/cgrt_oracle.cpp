@@ -543,13 +543,13 @@ struct Shader {
         if (c <= 0) return mk(0, 0, 0);
         return l.color * material_kd(m) * c;
     }
-    // main.cpp:61-82; pow(float, float) -> std::pow float overload is NOT selected for the
-    // unqualified call (fundamental types, no ADL): ::pow(double,double), narrowed by the vec3 multiply.
+    // main.cpp:61-82.  `light.color * ks * pow(specularCos, shininess)` only compiles when pow(float, float)
+    // yields float (glm's vec3 * scalar is a template on the element type), i.e. the float overload: powf.
     V3 specular(const Ray& r, const PointLight& l, V3 toLight, const HitState& h, const Mat& m) const {
         V3 refl = normalize3(reflect3(r.d, h.normal));
         float c = dot3(refl, toLight);
         if (c <= 0) return mk(0, 0, 0);
-        float p = (float)std::pow((double)c, (double)m.v[6]);
+        float p = std::pow(c, m.v[6]);
         return l.color * material_ks(m) * p;
     }
     // main.cpp:160-235 (point-light loop :219-232)
