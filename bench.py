@@ -89,13 +89,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one rank per GPU; CGRT_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the N>1 path on a 1-GPU box
+    backend = os.environ.get("CGRT_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = entry.load_package()
     from cg_raytracer_amd import tiling
@@ -142,7 +148,7 @@ def main():
     rs = pkg.record_sizes()
     alg_bytes = cnt["inner_visits"] * rs["node"] + cnt["tri_tests"] * rs["tri"] + cnt["sub_visits"] * rs["sub"] + cnt["rays"] * rs["hit"]
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall_max = float(wall_t.item())

@@ -44,7 +44,10 @@ struct alignas(16) SubNode {
 static const uint32_t SUB_RUN_MAX = 32;            // records per run
 static const uint32_t SUB_MAX_RECORDS = 1u << 26;  // run references address records with 26 bits
 static_assert(sizeof(SubNode) == 64, "SubNode must be 64 B");
-static const int SUB_MAX_DEPTH = 8;    // per-ray sub-stack never exceeds this many entries
+#ifndef CGRT_SUB_MAX_DEPTH
+#define CGRT_SUB_MAX_DEPTH 8
+#endif
+static const int SUB_MAX_DEPTH = CGRT_SUB_MAX_DEPTH;  // per-ray sub-stack never exceeds this many entries
 static const int SUB_LEAF_TRIS = 3;    // target triangles per sub-leaf (1..4 measure within 2 %; 3 was best on the dragon frame)
 
 // One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent
