@@ -109,6 +109,8 @@ def main():
     W, H = tiling.frame_for_world(world)
     if args.width and args.height:
         W, H = args.width, args.height
+    if os.environ.get("CGRT_PRIMARY_MODE"):  # experiment knob: 0 = wave per tile, 1 = persistent waves with lane refill
+        pkg.set_primary_mode(int(os.environ["CGRT_PRIMARY_MODE"]))
     if os.environ.get("CGRT_SUB_LEAF"):  # experiment knob: triangles per in-leaf accelerator run
         pkg.set_leaf_accel(True, int(os.environ["CGRT_SUB_LEAF"]))
     sd = pkg.scenes.make_dragon(args.tris)

@@ -88,7 +88,7 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/cgrt.h declares
 EXPORTS = [
-    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
+    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
     "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
         f.argtypes = [vp]
     L.cgrt_set_leaf_accel.argtypes = [i32, i32]
     L.cgrt_num_subnodes.argtypes = [vp]
+    L.cgrt_set_primary_mode.argtypes = [i32]
     L.cgrt_get_nodes.argtypes = [vp, vp, vp]
     L.cgrt_leaf_prims.argtypes = [vp, i32, vp, u32]
     L.cgrt_leaf_prims.restype = C.c_int64
@@ -173,6 +174,11 @@ def record_sizes() -> dict:
 def set_leaf_accel(enabled: bool = True, sub_leaf_tris: int = 0) -> None:
     """Process-wide build option for scenes created afterwards (results are identical either way)."""
     _check(lib().cgrt_set_leaf_accel(1 if enabled else 0, sub_leaf_tris))
+
+
+def set_primary_mode(mode: int) -> None:
+    """0 = one wave per 8x8 tile, 1 = persistent waves with lane refill (same results)."""
+    _check(lib().cgrt_set_primary_mode(int(mode)))
 
 
 def device_count() -> int:

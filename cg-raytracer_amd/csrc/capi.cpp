@@ -25,6 +25,7 @@ namespace {
 
 thread_local std::string g_err;
 BuildOptions g_build_options;  // process-wide, set through cgrt_set_leaf_accel before cgrt_scene_create
+int g_primary_mode = 0;        // cgrt_set_primary_mode: 0 = one wave per tile, 1 = persistent waves with lane refill
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -120,11 +121,14 @@ struct CgrtScene {
     void* d_tri_normals = nullptr;
     void* d_spheres = nullptr;
     unsigned long long* d_counters = nullptr;
+    unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, one per launch in flight
+    unsigned launch_seq = 0;
+    unsigned persistent_blocks = 1024;  // 4 workgroups per CU
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, (void*)d_counters})
+        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, (void*)d_counters, (void*)d_queues})
             if (p) (void)hipFree(p);
     }
 };
@@ -214,6 +218,17 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
             delete s;
             return hip_fail(e, "hipMalloc(counters)");
         }
+        e = hipMalloc((void**)&s->d_queues, 8 * CGRT_QUEUE_BLOCK_WORDS * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(s->d_queues, 0, 8 * CGRT_QUEUE_BLOCK_WORDS * sizeof(unsigned int));
+        if (e != hipSuccess) {
+            delete s;
+            return hip_fail(e, "hipMalloc(queues)");
+        }
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                s->persistent_blocks = (unsigned)prop.multiProcessorCount * 4u;
+        }
         s->device_bytes = total;
         SceneDev& D = s->dev;
         D.packets = static_cast<const NodePacket*>(s->d_records);
@@ -249,6 +264,11 @@ int cgrt_set_leaf_accel(int enabled, int sub_leaf_tris) {
     if (sub_leaf_tris < 0 || sub_leaf_tris > 64) return fail(CGRT_E_ARG, "sub_leaf_tris must be in 0..64 (0 = default)");
     g_build_options.leaf_accel = enabled != 0;
     g_build_options.sub_leaf_tris = sub_leaf_tris ? sub_leaf_tris : SUB_LEAF_TRIS;
+    return CGRT_OK;
+}
+int cgrt_set_primary_mode(int mode) {
+    if (mode != 0 && mode != 1) return fail(CGRT_E_ARG, "mode must be 0 (wave per tile) or 1 (persistent waves, lane refill)");
+    g_primary_mode = mode;
     return CGRT_OK;
 }
 int cgrt_num_subnodes(const CgrtScene* s) { return s ? (int)s->bvh.subnodes.size() : fail(CGRT_E_ARG, "scene is NULL"); }
@@ -328,8 +348,14 @@ int cgrt_trace_primary_device(CgrtScene* s, const CgrtCamera* cam, int W, int H,
     FrameDev F;
     if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr,
-                                 static_cast<hipStream_t>(stream)));
+    if (g_primary_mode == 1) {
+        unsigned int* q = s->d_queues + CGRT_QUEUE_BLOCK_WORDS * (s->launch_seq++ & 7u);
+        HIP_TRY(launch_trace_primary_persistent(s->dev, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr, q,
+                                                s->persistent_blocks, static_cast<hipStream_t>(stream)));
+    } else {
+        HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr,
+                                     static_cast<hipStream_t>(stream)));
+    }
     return CGRT_OK;
 }
 
@@ -394,7 +420,13 @@ int cgrt_count_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     DevBuf dh;
     HIP_TRY(dh.alloc((size_t)W * (size_t)H * sizeof(CgrtHit)));
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
-    HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, dh.as<CgrtHitDev>(), nullptr, s->d_counters, nullptr));
+    if (g_primary_mode == 1) {
+        unsigned int* q = s->d_queues + CGRT_QUEUE_BLOCK_WORDS * (s->launch_seq++ & 7u);
+        HIP_TRY(launch_trace_primary_persistent(s->dev, make_camera(*cam), F, dh.as<CgrtHitDev>(), nullptr, s->d_counters, q,
+                                                s->persistent_blocks, nullptr));
+    } else {
+        HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, dh.as<CgrtHitDev>(), nullptr, s->d_counters, nullptr));
+    }
     return read_counters(s, out);
 }
 

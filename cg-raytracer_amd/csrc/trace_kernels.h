@@ -7,6 +7,8 @@
 
 namespace cgrt {
 
+static const unsigned CGRT_QUEUE_BLOCK_WORDS = 32 * 9;
+
 // Device mirror of CgrtHit (include/cgrt.h), 16 B.
 struct CgrtHitDev {
     float t;
@@ -18,6 +20,9 @@ struct CgrtHitDev {
 // counters (optional): 5 x u64 device words {rays, inner_visits, leaf_visits, tri_tests, sub_visits}, accumulated.
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
                                 unsigned long long* counters, hipStream_t stream);
+// persistent variant: queue = CGRT_QUEUE_BLOCK_WORDS zeroed u32 (8 heads + exit counter, one 128-B line each) owned by this launch; blocks = persistent grid size
+hipError_t launch_trace_primary_persistent(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
+                                           unsigned long long* counters, unsigned int* queue, unsigned blocks, hipStream_t stream);
 // diagnostic: stamps = 4 x ntiles_rank u64 {memtime start, end, memrealtime start, end} per wave
 hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits,
                                         unsigned long long* stamps, hipStream_t stream);

@@ -19,6 +19,7 @@
 // denormals on -- see cgrt_math.h for why.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "cgrt_layout.h"
@@ -324,117 +325,147 @@ __device__ __forceinline__ bool ray_box_fast(const F3 lo, const F3 hi, const F3 
     return !((tIn > tOut) || (tOut < 0.0f)) && !(cur >= t);
 }
 
-// Ordered closest-hit walk of the reference tree for one ray ("while-while": every lane first advances
-// through inner nodes until it stands on a leaf or has nothing left, then the leaf lanes scan together;
-// a lane never waits on another lane's leaf scan to take an inner step and vice versa).
-//   t        in/out ray.t
-//   hit_rec  index of the last accepted triangle's TriRecord (REF_NONE if none)
+// Ordered closest-hit walk of the reference tree for one ray, resumable: walk_begin() runs the root gate,
+// walk_round() advances the ray by one "round" -- inner nodes of the reference tree until the lane stands on a
+// leaf (or has nothing left: returns true), then that leaf's scan.  "while-while": inside a round a lane never
+// waits on another lane's leaf scan to take an inner step and vice versa.  The plain kernels loop over rounds
+// until done; the persistent kernel refills finished lanes with new rays between rounds.
+struct Walk {
+    F3 o, d;
+    float t;           // ray.t
+    uint32_t hit_rec;  // record of the last accepted triangle (REF_NONE if none)
+    uint32_t cur;      // reference-tree node the lane stands on (REF_NONE: pop)
+    int sp;
+    RayPre P;
+    RayFast R;
+};
+
+// intersectDataStructure, bvh.cpp:831-844.  Returns false when the ray does not enter the tree at all.
+__device__ __forceinline__ bool walk_begin(const SceneDev& S, Walk& W) {
+    W.hit_rec = REF_NONE;
+    W.cur = REF_NONE;
+    W.sp = 0;
+    if (S.root_ref == REF_NONE) return false;
+    const F3 lo = f3(S.root_box.lo[0], S.root_box.lo[1], S.root_box.lo[2]);
+    const F3 hi = f3(S.root_box.hi[0], S.root_box.hi[1], S.root_box.hi[2]);
+    float tb;
+    // (the box test's write to ray.t is undone by the reference, :838)
+    if (!(starts_in_box(W.o, lo, hi) || ray_box(lo, hi, W.o, W.d, W.t, tb))) return false;
+    W.cur = S.root_ref;
+    W.P = make_raypre(S, W.o, W.d, W.t);
+    W.R = make_rayfast(S, W.o, W.d);
+    return true;
+}
+
 template <bool COUNT>
-__device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
-                                             uint32_t* __restrict__ stk, LaneCounters& cnt) {
-    uint32_t cur = REF_NONE;
-    if (S.root_ref != REF_NONE) {
-        // intersectDataStructure, bvh.cpp:831-844 (the box test's write to ray.t is undone there)
-        const F3 lo = f3(S.root_box.lo[0], S.root_box.lo[1], S.root_box.lo[2]);
-        const F3 hi = f3(S.root_box.hi[0], S.root_box.hi[1], S.root_box.hi[2]);
-        float tb;
-        if (starts_in_box(o, lo, hi) || ray_box(lo, hi, o, d, t, tb)) cur = S.root_ref;
-    }
-    if (cur == REF_NONE) return;
-    const RayPre P = make_raypre(S, o, d, t);
-    const RayFast R = make_rayfast(S, o, d);
-    int sp = 0;
+__device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t* __restrict__ stk, LaneCounters& cnt) {
+    const F3 o = W.o, d = W.d;
+    uint32_t cur = W.cur;
+    int sp = W.sp;
+    // ---- topology phase: intersectNonLeaf steps until a leaf is reached ----
     for (;;) {
-        // ---- topology phase: intersectNonLeaf steps until a leaf is reached ----
-        bool done = false;
-        for (;;) {
-            if (cur == REF_NONE) {
-                bool found = false;
-                while (sp > 0) {
-                    sp -= 2;
-                    const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
-                    const uint32_t r = stk[sp * CGRT_BLOCK];
-                    if (!(t < ts)) {  // bvh.cpp:582: skip the deferred child iff ray.t < tSecond
-                        cur = r;
-                        found = true;
-                        break;
-                    }
-                }
-                if (!found) {
-                    done = true;
+        if (cur == REF_NONE) {
+            bool found = false;
+            while (sp > 0) {
+                sp -= 2;
+                const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
+                const uint32_t r = stk[sp * CGRT_BLOCK];
+                if (!(W.t < ts)) {  // bvh.cpp:582: skip the deferred child iff ray.t < tSecond
+                    cur = r;
+                    found = true;
                     break;
                 }
             }
-            if (cur & REF_LEAF) break;
-            // intersectNonLeaf, bvh.cpp:715-736
-            if (COUNT) {
-                cnt.inner++;
-                if (first_active_lane()) cnt.w_inner++;
+            if (!found) {
+                W.cur = REF_NONE;
+                W.sp = 0;
+                return true;
             }
-            const float4* q = reinterpret_cast<const float4*>(S.packets + cur);
-            const float4 a = q[0], b = q[1], c = q[2];
-            const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
-            const F3 llo = f3(a.x, a.y, a.z), lhi = f3(a.w, b.x, b.y);
-            const F3 rlo = f3(b.z, b.w, c.x), rhi = f3(c.y, c.z, c.w);
-            float tL = -1.0f, tR = -1.0f, tb;
-            bool inL, inR;
-            if (R.fd) {
-                if (ray_box_fast(llo, lhi, o, d, R, t, tb, inL)) tL = tb;
-                if (ray_box_fast(rlo, rhi, o, d, R, t, tb, inR)) tR = tb;
-            } else {
-                if (ray_box(llo, lhi, o, d, t, tb)) tL = tb;
-                if (ray_box(rlo, rhi, o, d, t, tb)) tR = tb;
-                inL = starts_in_box(o, llo, lhi);
-                inR = starts_in_box(o, rlo, rhi);
+        }
+        if (cur & REF_LEAF) break;
+        // intersectNonLeaf, bvh.cpp:715-736
+        if (COUNT) {
+            cnt.inner++;
+            if (first_active_lane()) cnt.w_inner++;
+        }
+        const float4* q = reinterpret_cast<const float4*>(S.packets + cur);
+        const float4 a = q[0], b = q[1], c = q[2];
+        const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
+        const F3 llo = f3(a.x, a.y, a.z), lhi = f3(a.w, b.x, b.y);
+        const F3 rlo = f3(b.z, b.w, c.x), rhi = f3(c.y, c.z, c.w);
+        float tL = -1.0f, tR = -1.0f, tb;
+        bool inL, inR;
+        if (W.R.fd) {
+            if (ray_box_fast(llo, lhi, o, d, W.R, W.t, tb, inL)) tL = tb;
+            if (ray_box_fast(rlo, rhi, o, d, W.R, W.t, tb, inR)) tR = tb;
+        } else {
+            if (ray_box(llo, lhi, o, d, W.t, tb)) tL = tb;
+            if (ray_box(rlo, rhi, o, d, W.t, tb)) tR = tb;
+            inL = starts_in_box(o, llo, lhi);
+            inR = starts_in_box(o, rlo, rhi);
+        }
+        uint32_t first = REF_NONE, second = REF_NONE;
+        float tsec = 0.0f;
+        if (inL && inR) {  // intersectDeeper :685-688, left then right, no culling
+            first = m.x;
+            second = m.y;
+            tsec = -__builtin_inff();
+        } else if (inL) {  // :689-692
+            first = m.x;
+            if (!(tR < 0)) {
+                second = m.y;
+                tsec = tR;
             }
-            uint32_t first = REF_NONE, second = REF_NONE;
-            float tsec = 0.0f;
-            if (inL && inR) {  // intersectDeeper :685-688, left then right, no culling
+        } else if (inR) {  // :693-696
+            first = m.y;
+            if (!(tL < 0)) {
+                second = m.x;
+                tsec = tL;
+            }
+        } else {  // intersectRayThatStartsOutsideBoxes :611-635
+            const bool ml = tL < 0, mr = tR < 0;
+            if (ml && mr) {
+            } else if (ml) {
+                first = m.y;
+            } else if (mr) {
+                first = m.x;
+            } else if (tL < tR) {
                 first = m.x;
                 second = m.y;
-                tsec = -__builtin_inff();
-            } else if (inL) {  // :689-692
-                first = m.x;
-                if (!(tR < 0)) {
-                    second = m.y;
-                    tsec = tR;
-                }
-            } else if (inR) {  // :693-696
+                tsec = tR;
+            } else {
                 first = m.y;
-                if (!(tL < 0)) {
-                    second = m.x;
-                    tsec = tL;
-                }
-            } else {  // intersectRayThatStartsOutsideBoxes :611-635
-                const bool ml = tL < 0, mr = tR < 0;
-                if (ml && mr) {
-                } else if (ml) {
-                    first = m.y;
-                } else if (mr) {
-                    first = m.x;
-                } else if (tL < tR) {
-                    first = m.x;
-                    second = m.y;
-                    tsec = tR;
-                } else {
-                    first = m.y;
-                    second = m.x;
-                    tsec = tL;
-                }
+                second = m.x;
+                tsec = tL;
             }
-            if (second != REF_NONE) {
-                stk[sp * CGRT_BLOCK] = second;
-                stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
-                sp += 2;
-            }
-            cur = first;
         }
-        if (done) break;
-        // ---- leaf phase ----
-        if (COUNT) cnt.leaf++;
-        scan_leaf<COUNT>(S, S.leaves[cur & ~REF_LEAF], o, d, P, t, hit_rec, stk, sp, cnt);
-        cur = REF_NONE;
+        if (second != REF_NONE) {
+            stk[sp * CGRT_BLOCK] = second;
+            stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
+            sp += 2;
+        }
+        cur = first;
     }
+    // ---- leaf phase ----
+    if (COUNT) cnt.leaf++;
+    scan_leaf<COUNT>(S, S.leaves[cur & ~REF_LEAF], o, d, W.P, W.t, W.hit_rec, stk, sp, cnt);
+    W.cur = REF_NONE;
+    W.sp = sp;
+    return false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
+                                          uint32_t* __restrict__ stk, LaneCounters& cnt) {
+    Walk W;
+    W.o = o;
+    W.d = d;
+    W.t = t;
+    if (walk_begin(S, W))
+        while (!walk_round<COUNT>(S, W, stk, cnt)) {
+        }
+    t = W.t;
+    hit_rec = W.hit_rec;
 }
 
 // Spheres (bvh.cpp:878-879), result assembly and the accepted hit's interpolated normal
@@ -565,6 +596,137 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
         }
     } else if (COUNT) {
         flush_counters(cnt, active, counters);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent primary-frame kernel: a fixed grid of waves (4 workgroups per CU) pulls 8x8-pixel tiles
+// from eight queues (one per blockIdx % 8 residue, i.e. per XCD under the observed placement; a wave
+// drains its home queue first, then steals from the others) and keeps its 64 lanes busy: between two
+// rounds of walk_round(), when at least CGRT_REFILL_MIN_IDLE lanes have finished their ray, the idle
+// lanes are handed the next pixels of the wave's current tile (ballot of the idle lanes, rank by
+// popcount of the lower lanes).  Rays that fail the root gate are written out at once and their lane is
+// refilled in the same pass, so after a refill the wave's active lanes all carry rays that actually
+// traverse.  Tiles are handed out in the same super-tile order as the plain kernel.
+// Every wave leaves when all queues are exhausted and its lanes are idle; no wave waits on another.
+// The queue block (8 heads + 1 exit counter, one 128-byte line each) is reset by the last wave to leave.
+#ifndef CGRT_REFILL_MIN_IDLE
+#define CGRT_REFILL_MIN_IDLE 16
+#endif
+#ifndef CGRT_QUEUE_CHUNK
+#define CGRT_QUEUE_CHUNK 1  // tiles taken per atomic; larger chunks were measured much slower (4: 2.4x, 16: 7x): hard tiles cluster
+#endif
+// Queue block layout: head q at word 32*q (each head on its own 128-byte line: atomics on one line serialise
+// at the memory side), exit counter at word 32*8.
+#define CGRT_QUEUE_WORDS (32 * 9)
+
+__device__ __forceinline__ uint32_t queue_units(const FrameDev& F, uint32_t q) {  // tiles in queue q
+    return q < F.nst_rank ? ((F.nst_rank - q + 7u) / 8u) * 64u : 0u;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trace_primary_persistent(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits,
+                                                   float* __restrict__ normals, unsigned long long* counters,
+                                                   unsigned int* __restrict__ queue, unsigned int total_waves) {
+    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    uint32_t* stk = s_stk + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t home = blockIdx.x & 7u;
+    LaneCounters cnt;
+    Walk W;
+    bool active = false;
+    size_t pix = 0;
+    // wave-uniform refill state
+    uint32_t tile_q = 0, tile_k = 0, next_pix = 64, tried = 0, chunk_left = 0;
+    bool exhausted = false;
+    uint32_t nrays = 0;
+    for (;;) {
+        unsigned long long act = __ballot(active);
+        if (!exhausted && (64 - __popcll(act)) >= CGRT_REFILL_MIN_IDLE) {
+            unsigned long long idle = ~act;
+            while (idle != 0ull) {
+                if (next_pix >= 64u) {  // next tile: rest of the chunk in hand, else home queue first, then the others in order
+                    bool got = false;
+                    if (chunk_left > 0u) {
+                        tile_k += 1u;
+                        chunk_left -= 1u;
+                        next_pix = 0;
+                        got = true;
+                    }
+                    while (!got && tried < 8u) {
+                        const uint32_t q = (home + tried) & 7u;
+                        uint32_t k = 0;
+                        if (lane == 0) k = atomicAdd(queue + 32u * q, (unsigned)CGRT_QUEUE_CHUNK);
+                        k = __builtin_amdgcn_readfirstlane(k);
+                        const uint32_t nq = queue_units(F, q);
+                        if (k < nq) {
+                            tile_q = q;
+                            tile_k = k;
+                            chunk_left = min((uint32_t)CGRT_QUEUE_CHUNK, nq - k) - 1u;
+                            next_pix = 0;
+                            got = true;
+                            break;
+                        }
+                        tried++;
+                    }
+                    if (!got) {
+                        exhausted = true;
+                        break;
+                    }
+                }
+                const uint32_t nidle = (uint32_t)__popcll(idle);
+                const uint32_t take = min(64u - next_pix, nidle);
+                const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                const bool mine = ((idle >> lane) & 1ull) && rank < take;
+                if (mine) {
+                    const uint32_t p = next_pix + rank;
+                    const uint32_t s_loc = tile_q + 8u * (tile_k >> 6);  // rank-local super-tile
+                    const uint32_t st = (uint32_t)F.rank + (uint32_t)F.nranks * s_loc;
+                    const int stx = (int)(st % (uint32_t)F.st_x), sty = (int)(st / (uint32_t)F.st_x);
+                    const int idx = (int)(tile_k & 63u);
+                    const int x = F.x0 + (stx * ST_TILES + (idx & 7)) * 8 + (int)(p & 7u);
+                    const int y = F.y0 + (sty * ST_TILES + (idx >> 3)) * 8 + (int)(p >> 3);
+                    if (x < F.x1 && y < F.y1) {
+                        if (COUNT) nrays++;
+                        pix = (size_t)y * F.W + x;
+                        primary_ray(C, F.W, F.H, x, y, W.o, W.d);
+                        W.t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
+                        if (walk_begin(S, W))
+                            active = true;
+                        else
+                            finish_ray(S, W.o, W.d, W.t, W.hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
+                    }
+                }
+                next_pix += take;
+                idle = ~__ballot(active);  // lanes whose ray died at the root gate are idle again
+                if (__popcll(idle) < CGRT_REFILL_MIN_IDLE && next_pix < 64u) break;
+            }
+            act = __ballot(active);
+        }
+        if (act == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (active) {
+            if (walk_round<COUNT>(S, W, stk, cnt)) {
+                finish_ray(S, W.o, W.d, W.t, W.hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
+                active = false;
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long v[5] = {nrays, cnt.inner, cnt.leaf, cnt.tri, cnt.sub};
+        for (int k = 0; k < 5; k++) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0 && x) atomicAdd(counters + k, x);
+        }
+    }
+    if (lane == 0) {
+        if (atomicAdd(queue + 32 * 8, 1u) == total_waves - 1u) {  // last wave out: leave the queue block clean
+            for (int q = 0; q < 9; q++) queue[32 * q] = 0u;
+        }
     }
 }
 
@@ -721,6 +883,19 @@ hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const Fra
         hipLaunchKernelGGL(k_trace_primary<true>, dim3(blocks), dim3(CGRT_BLOCK), lds_pad, stream, S, C, F, hits, normals, counters);
     else
         hipLaunchKernelGGL(k_trace_primary<false>, dim3(blocks), dim3(CGRT_BLOCK), lds_pad, stream, S, C, F, hits, normals, counters);
+    return hipGetLastError();
+}
+hipError_t launch_trace_primary_persistent(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
+                                           unsigned long long* counters, unsigned int* queue, unsigned blocks, hipStream_t stream) {
+    if (F.nst_rank == 0) return hipSuccess;
+    const unsigned long long tiles = (unsigned long long)((F.nst_rank + 7u) / 8u) * 8u * 64u;
+    unsigned b = (unsigned)std::min<unsigned long long>(blocks, (tiles + 3) / 4);
+    b = std::max(8u, (b + 7u) & ~7u);
+    const unsigned waves = b * (CGRT_BLOCK / 64);
+    if (counters)
+        hipLaunchKernelGGL(k_trace_primary_persistent<true>, dim3(b), dim3(CGRT_BLOCK), 0, stream, S, C, F, hits, normals, counters, queue, waves);
+    else
+        hipLaunchKernelGGL(k_trace_primary_persistent<false>, dim3(b), dim3(CGRT_BLOCK), 0, stream, S, C, F, hits, normals, counters, queue, waves);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits,

@@ -93,6 +93,9 @@ void cgrt_scene_destroy(CgrtScene* scene);
  * applies to scenes created afterwards.  sub_leaf_tris: triangles per accelerator leaf, 0 = default (4). */
 int cgrt_set_leaf_accel(int enabled, int sub_leaf_tris);
 int cgrt_num_subnodes(const CgrtScene* scene);
+/* Scheduling of the fused primary-frame kernel (results are identical; tested): 0 = one wave per 8x8 tile,
+ * 1 = persistent waves that pull tiles from per-XCD queues and refill finished lanes.  Process-wide. */
+int cgrt_set_primary_mode(int mode);
 
 /* BoundingVolumeHierarchy::numLevels() (bvh.cpp:214-224). */
 int cgrt_num_levels(const CgrtScene* scene);

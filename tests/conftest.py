@@ -20,7 +20,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     p = entry.load_package()
-    if not os.path.exists(p.LIB_PATH):
+    if not (os.path.exists(p.LIB_PATH) and os.path.exists(p.HOST_LIB_PATH)):
         p.build_native()
     return p
 

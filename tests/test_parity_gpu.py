@@ -193,6 +193,51 @@ def test_intersect_matches_oracle_fresh_rays(pkg, orc, scene_data, name):
         _assert_hits_equal(hits, normals, o.intersect(fam[k]), f"{name}/{k}")
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_multi_mesh_scenes_with_degenerates(pkg, orc, seed):
+    """Many meshes of very different sizes (multi-mesh nodes and leaves, single-triangle meshes), zero-area and
+    duplicated triangles, a NaN and an infinite vertex coordinate: builder and traversal against the oracle."""
+    rng = np.random.RandomState(seed)
+    nmesh = rng.randint(5, 40)
+    rows, tris, tm = [], [], []
+    for m in range(nmesh):
+        nt = int(rng.choice([1, 1, 2, 3, 7, 40, 300, 1500]))
+        c = rng.uniform(-0.8, 0.8, 3)
+        sz = rng.uniform(0.02, 0.5)
+        for _ in range(nt):
+            p0 = c + rng.uniform(-sz, sz, 3)
+            tri = np.stack([p0, p0 + rng.uniform(-0.1, 0.1, 3), p0 + rng.uniform(-0.1, 0.1, 3)])
+            kind = rng.randint(0, 40)
+            if kind == 0:
+                tri[2] = tri[1]  # zero area
+            elif kind == 1 and tris:
+                tri = np.asarray(rows[-3:])[:, 0:3]  # exact duplicate of the previous triangle
+            base = len(rows)
+            nrm = rng.normal(size=(3, 3))
+            for k in range(3):
+                rows.append(np.concatenate([tri[k], nrm[k] / np.linalg.norm(nrm[k])]))
+            tris.append((base, base + 1, base + 2))
+            tm.append(m)
+    pn = np.asarray(rows, np.float32)
+    if seed == 2:
+        pn[5, 1] = np.nan
+        pn[len(pn) // 2, 0] = np.inf
+    sd = pkg.scenes.SceneData(pos_nrm=pn, tri=np.asarray(tris, np.uint32), tri_mesh=np.asarray(tm, np.uint32),
+                              materials=rng.uniform(0, 1, (nmesh, 8)).astype(np.float32))
+    o, sc = orc.OracleScene(sd), pkg.Scene(sd)
+    m1, b1 = o.nodes()
+    m2, b2 = sc.nodes()
+    assert np.array_equal(m1, m2) and same_bits(b1, b2).all()
+    finite_boxes = b1[np.isfinite(b1).all(1)]
+    W = H = 80
+    fam = rayfam.families(sd, finite_boxes, orc.generate_rays(pkg.scenes.default_camera(W, H), W, H), rng=rng, n_random=2500)
+    rays = rayfam.concat(fam)
+    rays = rays[np.isfinite(rays).all(1) | (rays[:, 6] == np.inf)]
+    hits, normals = sc.intersect(_rays(pkg, rays))
+    _assert_hits_equal(hits, normals, o.intersect(rays), f"random scene {seed}")
+    assert hits["hit"].mean() > 0.1
+
+
 def test_f4_false_misses_reproduced_on_gpu(pkg, scene_data):
     sc = pkg.Scene(scene_data("cube"))
     rays = pkg.as_rays(np.broadcast_to(np.float32(rayfam.F4_ORIGIN), (3, 3)), np.float32(rayfam.F4_DIRS))
@@ -275,6 +320,31 @@ def test_trace_primary_tiles_partition_the_image(pkg, scene_data):
     inside = (xx >= 40) & (xx < 211) & (yy >= 16) & (yy < 100)
     assert np.array_equal(~np.isnan(part["t"]), inside)
     assert part[inside].tobytes() == full[inside].tobytes()
+
+
+@pytest.mark.parametrize("W,H,nranks", [(640, 360, 1), (333, 217, 1), (500, 301, 3), (64, 64, 1), (1, 1, 1)])
+def test_persistent_kernel_same_results(pkg, orc, W, H, nranks):
+    """Primary mode 1 (persistent waves pulling tiles from per-XCD queues, finished lanes refilled) must write
+    exactly what mode 0 (one wave per tile) writes -- scheduling is a speed matter only -- and what the oracle says."""
+    sd = pkg.scenes.make_dragon(40_000)
+    cam = pkg.scenes.default_camera(W, H)
+    sc = pkg.Scene(sd)
+    ref = orc.OracleScene(sd).intersect(sc.generate_rays(cam, W, H))
+    try:
+        for rank in range(nranks):
+            pkg.set_primary_mode(0)
+            h0, n0 = sc.trace_primary(cam, W, H, rank=rank, nranks=nranks, want_normals=True)
+            c0 = sc.count_primary(cam, W, H, rank=rank, nranks=nranks)
+            pkg.set_primary_mode(1)
+            for rep in range(3):  # queue blocks are reused round-robin and must come back clean
+                h1, n1 = sc.trace_primary(cam, W, H, rank=rank, nranks=nranks, want_normals=True)
+                assert h1.tobytes() == h0.tobytes() and n1.tobytes() == n0.tobytes()
+            c1 = sc.count_primary(cam, W, H, rank=rank, nranks=nranks)
+            assert c1["rays"] == c0["rays"] and c1["inner_visits"] == c0["inner_visits"] and c1["leaf_visits"] == c0["leaf_visits"]
+            own = ~np.isnan(h1["t"])
+            _assert_hits_equal(h1[own], n1[own], ref[own], f"persistent {W}x{H} rank {rank}/{nranks}")
+    finally:
+        pkg.set_primary_mode(0)
 
 
 def test_counters_match_oracle_replay(pkg, orc):
