@@ -51,7 +51,16 @@ namespace cgrt {
 // MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 2 slots (ref, entry parameter), at most SUB_MAX_DEPTH.
 #define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + CGRT_SUB_SLOTS * SUB_MAX_DEPTH)
 
+#ifndef CGRT_STAMP_SUB
+#define CGRT_STAMP_SUB 0  // diagnostic build: in-loop s_memtime stamps of the accelerator node step (load wait vs compute)
+#endif
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 struct LaneCounters {
+    unsigned long long c_wait = 0, c_comp = 0, c_tri = 0;  // CGRT_STAMP_SUB only
     uint32_t inner = 0, leaf = 0, tri = 0, sub = 0;
     // wave-level iteration counts (diagnostic): in every executed loop body exactly one active lane adds 1,
     // so the sum over lanes is the number of times the WAVE ran that body
@@ -204,9 +213,17 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
                     cnt.sub++;
                     if (first_active_lane()) cnt.w_sub++;
                 }
+#if CGRT_STAMP_SUB
+                const unsigned long long st_a = stamp_now();
+#endif
                 const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
                 const float4 a = q[0], b = q[1], c = q[2];
                 const uint2 m = *reinterpret_cast<const uint2*>(q + 3);
+#if CGRT_STAMP_SUB
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long st_b = stamp_now();
+                if (COUNT && first_active_lane()) cnt.c_wait += st_b - st_a;
+#endif
                 float tn0, tf0, tn1, tf1;
                 slab_cons(P, f3(a.x, a.y, a.z), f3(a.w, b.x, b.y), tn0, tf0);
                 slab_cons(P, f3(b.z, b.w, c.x), f3(c.y, c.z, c.w), tn1, tf1);
@@ -225,9 +242,24 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
                     sp += CGRT_SUB_SLOTS;
                 }
                 cur = (h0 || h1) ? rn : REF_NONE;
+#if CGRT_STAMP_SUB
+                {
+                    const unsigned long long st_c = stamp_now();
+                    if (COUNT && first_active_lane()) cnt.c_comp += st_c - st_b;
+                }
+#endif
             }
             // ---- triangle phase ----
+#if CGRT_STAMP_SUB
+            const unsigned long long st_t = stamp_now();
+#endif
             if (cur != REF_NONE) test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, L, cnt);
+#if CGRT_STAMP_SUB
+            {
+                const unsigned long long st_u = stamp_now();
+                if (COUNT && first_active_lane()) cnt.c_tri += st_u - st_t;
+            }
+#endif
             // ---- pop ----
             cur = REF_NONE;
 #if CGRT_SUB_TN
@@ -585,6 +617,11 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
                 const uint32_t other = __shfl_down(v[k], off, 64);
                 v[k] = k < 7 ? v[k] + other : (v[k] > other ? v[k] : other);  // sums, then per-lane maxima
             }
+#if CGRT_STAMP_SUB
+        unsigned long long cw[3] = {cnt.c_wait, cnt.c_comp, cnt.c_tri};
+        for (int k = 0; k < 3; k++)
+            for (int off = 32; off > 0; off >>= 1) cw[k] += __shfl_down(cw[k], off, 64);
+#endif
         if (lane == 0) {
             unsigned long long* p = counters + 16ull * wave_global;
             p[0] = st0;
@@ -593,6 +630,11 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
             p[3] = rt1;
             for (int k = 0; k < 11; k++) p[4 + k] = v[k];
             p[15] = nactive;
+#if CGRT_STAMP_SUB
+            p[12] = cw[0];  // replaces max_leaf: wave-summed cycles waiting for the node record
+            p[13] = cw[1];  // replaces max_tri: ... computing the node step
+            p[14] = cw[2];  // replaces max_sub: ... in the triangle phase
+#endif
         }
     } else if (COUNT) {
         flush_counters(cnt, active, counters);

@@ -40,3 +40,8 @@ m = heavy & (it > 0)
 A = np.stack([t[m, 8], t[m, 9], t[m, 10], np.ones(m.sum())], 1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(A, dur[m].astype(np.float64), rcond=None)
 print("least-squares cycles per wave-iteration: inner %.0f sub %.0f tri %.0f const %.0f" % tuple(coef))
+
+if os.environ.get("STAMP_SUB"):
+    for i in order[:6]:
+        print(int(i), "cycles", int(dur[i]), "node-step load wait", int(t[i, 12]), "node-step compute", int(t[i, 13]), "tri phase", int(t[i, 14]),
+              "per sub wave-iter: wait %.0f comp %.0f; per tri wave-iter %.0f" % (t[i, 12] / max(1, t[i, 9]), t[i, 13] / max(1, t[i, 9]), t[i, 14] / max(1, t[i, 10])))
