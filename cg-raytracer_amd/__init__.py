@@ -50,6 +50,11 @@ class Counters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class RenderStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("reflection_rays", C.c_uint64), ("levels", C.c_int32),
+                ("device_ms", C.c_float)]
+
+
 class Camera(C.Structure):
     _fields_ = [
         ("look_at", C.c_float * 3),
@@ -90,7 +95,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_record_sizes",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
 ]  # fmt: skip
@@ -127,6 +132,7 @@ def lib() -> C.CDLL:
     L.cgrt_trace_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp]
     L.cgrt_trace_primary_device.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp, vp]
     L.cgrt_generate_rays.argtypes = [vp, C.POINTER(Camera)] + [i32] * 6 + [vp]
+    L.cgrt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats)]
     L.cgrt_count_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [C.POINTER(Counters)]
     L.cgrt_count_batch.argtypes = [vp, vp, u64, C.POINTER(Counters)]
     L.cgrt_debug_fastdiv_check.argtypes = [i32, vp, vp, u64, vp, vp]
@@ -276,6 +282,15 @@ class Scene:
                 C.c_void_p(stream) if stream else None,
             )
         )  # fmt: skip
+
+    def render(self, cam, W: int, H: int, lights=None, max_level: int = 2):
+        """cgrt_render: the whole shading/recursion driver on the device. Returns (rgb[W*H,3], stats dict)."""
+        lights = _f32(self.sd.point_lights if lights is None else lights, (-1, 6))
+        rgb = np.zeros((W * H, 3), np.float32)
+        st = RenderStats()
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_render(self._h, C.byref(c), W, H, _ptr(lights), len(lights), max_level, _ptr(rgb), C.byref(st)))
+        return rgb, {k: getattr(st, k) for k, _ in st._fields_}
 
     def generate_rays(self, cam, W: int, H: int, rect=None) -> np.ndarray:
         x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)

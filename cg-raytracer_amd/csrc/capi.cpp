@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <utility>
 #include <cstring>
 #include <new>
 #include <string>
@@ -120,6 +121,8 @@ struct CgrtScene {
     void* d_leaves = nullptr;
     void* d_tri_normals = nullptr;
     void* d_spheres = nullptr;
+    void* d_materials = nullptr;  // nmesh x 8 floats, for the shading wavefront
+    uint32_t nmesh = 0;
     unsigned long long* d_counters = nullptr;
     unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, one per launch in flight
     unsigned launch_seq = 0;
@@ -128,7 +131,7 @@ struct CgrtScene {
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, (void*)d_counters, (void*)d_queues})
+        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, (void*)d_counters, (void*)d_queues})
             if (p) (void)hipFree(p);
     }
 };
@@ -207,6 +210,11 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
                 return hip_fail(e, "uploading the record array");
             }
             total += nrec * 64;
+        }
+        s->nmesh = nmesh;
+        if ((rc = upload(hs.materials, &s->d_materials, total))) {
+            delete s;
+            return rc;
         }
         if ((rc = upload(s->bvh.leaves, &s->d_leaves, total)) || (rc = upload(s->bvh.tri_normals, &s->d_tri_normals, total)) ||
             (rc = upload(s->bvh.spheres, &s->d_spheres, total))) {
@@ -460,6 +468,81 @@ int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters
     HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
     HIP_TRY(launch_trace_batch(s->dev, dr.as<float>(), n, dh.as<CgrtHitDev>(), nullptr, s->d_counters, nullptr));
     return read_counters(s, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// renderRayTracing / getFinalColor (src/main.cpp:298-310, :648-720) as a device wavefront
+int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level, float* rgb,
+                CgrtRenderStats* stats) {
+    if (!s || !cam || !rgb || (nlights && !lights)) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    if (W <= 0 || H <= 0 || max_level < 0 || max_level > 16) return fail(CGRT_E_ARG, "bad frame size or recursion depth");
+    HIP_TRY(hipSetDevice(s->device));
+    const unsigned long long n = (unsigned long long)W * H;
+    const unsigned L = nlights;
+    DevBuf rays, nrays, hits, normals, srays, shits, sdist, dlights, levels, drgb, dstats;
+    HIP_TRY(rays.alloc(n * 28));
+    HIP_TRY(nrays.alloc(n * 28));
+    HIP_TRY(hits.alloc(n * sizeof(CgrtHit)));
+    HIP_TRY(normals.alloc(n * 12));
+    HIP_TRY(srays.alloc(n * L * 28));
+    HIP_TRY(shits.alloc(n * L * sizeof(CgrtHit)));
+    HIP_TRY(sdist.alloc(n * L * 4));
+    HIP_TRY(dlights.alloc((size_t)L * 24));
+    HIP_TRY(levels.alloc((size_t)(max_level > 0 ? max_level : 1) * n * 32));
+    HIP_TRY(drgb.alloc(n * 12));
+    HIP_TRY(dstats.alloc(3 * sizeof(unsigned long long)));
+    if (L) HIP_TRY(hipMemcpy(dlights.p, lights, (size_t)L * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dstats.p, 0, 3 * sizeof(unsigned long long)));
+    CgrtRenderStats st{};
+    FrameDev F;
+    if (!make_frame(W, H, 0, 0, W, H, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame");
+    const CameraDev C = make_camera(*cam);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    int nlev = 0;
+    if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
+        HIP_TRY(launch_generate_rays(C, W, H, 0, 0, W, H, rays.as<float>(), nullptr));
+        HIP_TRY(launch_trace_primary(s->dev, C, F, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
+        st.primary_rays = n;
+        float* cur = rays.as<float>();
+        float* nxt = nrays.as<float>();
+        for (int level = 0; level < max_level; level++) {
+            const int spawn = level + 1 < max_level;
+            HIP_TRY(launch_spawn_shadow(cur, hits.as<CgrtHitDev>(), n, dlights.as<float>(), L, srays.as<float>(), sdist.as<float>(), nullptr));
+            HIP_TRY(launch_trace_batch(s->dev, srays.as<float>(), n * L, shits.as<CgrtHitDev>(), nullptr, nullptr, nullptr));
+            HIP_TRY(launch_shade(cur, hits.as<CgrtHitDev>(), normals.as<float>(), shits.as<CgrtHitDev>(), sdist.as<float>(), n,
+                                 static_cast<const float*>(s->d_materials), dlights.as<float>(), L, spawn,
+                                 levels.as<float>() + (size_t)level * n * 8, nxt, dstats.as<unsigned long long>(), nullptr));
+            nlev = level + 1;
+            unsigned long long h[3];
+            HIP_TRY(hipMemcpy(h, dstats.p, sizeof(h), hipMemcpyDeviceToHost));  // also the level's sync point
+            const unsigned long long spawned = h[2] - st.reflection_rays;
+            st.shadow_rays = h[1];
+            st.reflection_rays = h[2];
+            if (!spawn || spawned == 0) break;
+            HIP_TRY(launch_trace_batch(s->dev, nxt, n, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
+            std::swap(cur, nxt);
+        }
+    }
+    if (nlev == 0) {
+        HIP_TRY(hipMemset(drgb.p, 0, n * 12));
+    } else {
+        HIP_TRY(launch_combine(levels.as<float>(), nlev, n, drgb.as<float>(), nullptr));
+    }
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    st.device_ms = ms;
+    st.levels = nlev;
+    HIP_TRY(hipMemcpy(rgb, drgb.p, n * 12, hipMemcpyDeviceToHost));
+    if (stats) *stats = st;
+    return CGRT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -131,6 +131,19 @@ int cgrt_trace_primary_device(CgrtScene* scene, const CgrtCamera* cam, int W, in
 int cgrt_generate_rays(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,
                        CgrtRay* rays);
 
+/* renderRayTracing / getFinalColor (src/main.cpp:298-310, :648-720) for a whole frame, entirely on the device: primary
+ * rays, then per recursion level the shadow rays of every hit (pointInShadow, :104-135), the Phong terms (:61-98,
+ * :219-232) and the mirror rays (shade, :241-264).  max_level = 2 is the reference (`level >= 2` -> black, :267).
+ * lights: nlights x 6 floats {position, color} (PointLight, scene.h:42-45); rgb: W*H*3 floats, index y*W+x, not
+ * y-flipped and not clamped (Screen::setPixel / writeBitmapToFile do that, screen.cpp:30-49).  Host pointers. */
+typedef struct CgrtRenderStats {
+    uint64_t primary_rays, shadow_rays, reflection_rays; /* rays that exist upstream (null rays of dead paths not counted) */
+    int32_t levels;                                      /* recursion levels actually evaluated */
+    float device_ms;                                     /* HIP-event time of all kernels of the frame */
+} CgrtRenderStats;
+int cgrt_render(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level,
+                float* rgb, CgrtRenderStats* stats);
+
 /* Work counters of the same traversal (separate instrumented launch; not part of any timed region). */
 int cgrt_count_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,
                        int rank, int nranks, CgrtCounters* out);

@@ -70,3 +70,32 @@ def test_config3_cornell_1080p_depth4(pkg, orc, scene_data):
     ref, _ = orc.OracleScene(sd).render(cam, W, H, sd.point_lights, max_level=4)
     assert np.abs(rgb.astype(np.float64) - ref).max() <= 1e-5
     assert st["primary"] == W * H and st["shadow"] > W * H // 10 and st["reflection"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,W,H,level", [("cornell", 480, 270, 2), ("cornell", 480, 270, 4), ("monkey", 256, 256, 2),
+                                            ("cube", 200, 200, 2), ("blob", 200, 150, 3), ("cornell", 64, 64, 0), ("cornell", 64, 64, 1)])
+def test_device_render_matches_oracle(pkg, orc, scene_data, name, W, H, level):
+    """cgrt_render: the whole driver on the device (shading kernels + batched traversal), RGB within 1e-5 of the
+    oracle's recursive restatement; the ray counts equal the recursive driver's."""
+    sd = scene_data(name)
+    cam = pkg.scenes.default_camera(W, H)
+    rgb, st = pkg.Scene(sd).render(cam, W, H, max_level=level)
+    ref, nrays = orc.OracleScene(sd).render(cam, W, H, sd.point_lights, max_level=level)
+    err = np.abs(rgb.astype(np.float64) - ref).max()
+    assert err <= 1e-5, f"max abs RGB error {err}"
+    assert st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"] == nrays
+    if level >= 2:
+        assert (ref.sum(1) > 0).mean() > 0.05
+
+
+@pytest.mark.gpu
+def test_config3_device_render_1080p_depth4(pkg, orc, scene_data):
+    """BASELINE.json config 3 on the device path: Cornell 1920x1080, recursion depth 4, RGB within 1e-5."""
+    sd = scene_data("cornell")
+    W, H = 1920, 1080
+    cam = pkg.scenes.default_camera(W, H)
+    rgb, st = pkg.Scene(sd).render(cam, W, H, max_level=4)
+    ref, nrays = orc.OracleScene(sd).render(cam, W, H, sd.point_lights, max_level=4)
+    assert np.abs(rgb.astype(np.float64) - ref).max() <= 1e-5
+    assert st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"] == nrays and st["levels"] >= 2
