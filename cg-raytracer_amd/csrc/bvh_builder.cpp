@@ -92,7 +92,7 @@ struct Builder {
 // the earlier scan position, and an origin-on-plane acceptance (t = 0, ray_tracing.cpp:43-47) goes to
 // the LAST such triangle.  So the kernel may test the triangles in any order -- and skip any triangle
 // that provably cannot be accepted -- as long as it applies that rule.  This builds, per reference
-// leaf, a binary BVH (surface-area heuristic, full sweep on every axis) used only to skip triangles
+// leaf, a 4-wide (or binary, CGRT_SUB_WIDTH) BVH (surface-area heuristic, full sweep on every axis) used only to skip triangles
 // whose padded box the ray misses or enters beyond the current best t.  The reference topology, its
 // visit order and its culling decisions above the leaves are untouched.
 //
@@ -133,12 +133,17 @@ struct SubBuilder {
         for (uint32_t i = b; i < e; i++) grow(r, tb[idx[i]]);
         return r;
     }
-    static uint64_t capacity(int depth_left, int leaf_tris) { return (uint64_t)leaf_tris << depth_left; }
+    // triangles a subtree with depth_left levels can hold
+    static uint64_t capacity(int depth_left, int leaf_tris) {
+        uint64_t c = (uint64_t)leaf_tris;
+        for (int i = 0; i < depth_left; i++) c *= (uint64_t)SUB_WIDTH;
+        return c;
+    }
 
-    // Splits idx[b, e) and returns the position of the split; depth_left >= 1 levels remain below.
-    uint32_t split(uint32_t b, uint32_t e, int depth_left) {
+    // Splits idx[b, e) in two (SAH, full sweep on every axis) and returns the position of the split; each side
+    // may hold at most `cap` triangles (what still fits under the remaining depth).
+    uint32_t split(uint32_t b, uint32_t e, uint64_t cap) {
         const uint32_t n = e - b;
-        const uint64_t cap = capacity(depth_left - 1, leaf_tris);  // what one child may still hold
         const uint32_t kmin = (uint32_t)std::max<int64_t>(1, (int64_t)n - (int64_t)cap);
         const uint32_t kmax = (uint32_t)std::min<uint64_t>(n - 1, cap);
         float best_cost = std::numeric_limits<float>::infinity();
@@ -173,22 +178,62 @@ struct SubBuilder {
         return b + best_k;
     }
 
-    // Builds the subtree over idx[b, e) (more than leaf_tris triangles) and returns its node index.
+    uint32_t child_ref(uint32_t base, uint32_t b, uint32_t e, int depth_left) {
+        const uint32_t cn = e - b;
+        // a child becomes a run of records when it is small enough or no depth is left
+        if (cn <= (uint32_t)leaf_tris || depth_left <= 0) return REF_LEAF | ((cn - 1) << 26) | (base + b);
+        return SUB_WIDTH == 4 ? build4(base, b, e, depth_left) : build(base, b, e, depth_left);
+    }
+
+    // 4-wide node over idx[b, e) (more than leaf_tris triangles): split in two, then each half again; the node is two
+    // consecutive SubNode records {children 0,1} {children 2,3}; a missing child has an empty box (never hit).
+    uint32_t build4(uint32_t base, uint32_t b, uint32_t e, int depth_left) {
+        const uint32_t me = (uint32_t)nodes.size();
+        nodes.push_back(SubNode());
+        nodes.push_back(SubNode());
+        const uint64_t cap1 = capacity(depth_left - 1, leaf_tris);
+        const uint32_t m = split(b, e, 2 * cap1);
+        uint32_t cb[4], ce[4];
+        int nc = 0;
+        const uint32_t hb[2] = {b, m}, he[2] = {m, e};
+        for (int h = 0; h < 2; h++) {
+            if (he[h] - hb[h] > (uint32_t)leaf_tris) {
+                const uint32_t q = split(hb[h], he[h], cap1);
+                cb[nc] = hb[h], ce[nc++] = q;
+                cb[nc] = q, ce[nc++] = he[h];
+            } else {
+                cb[nc] = hb[h], ce[nc++] = he[h];
+            }
+        }
+        Box6 box[4];
+        uint32_t ref[4];
+        for (int c = 0; c < 4; c++) {
+            if (c < nc) {
+                box[c] = range_box(cb[c], ce[c]);
+                ref[c] = child_ref(base, cb[c], ce[c], depth_left - 1);
+            } else {
+                box[c] = empty_box();
+                ref[c] = REF_NONE;
+            }
+        }
+        for (int r = 0; r < 2; r++) {
+            SubNode& N = nodes[me + r];
+            std::memcpy(N.box0, &box[2 * r], 24);
+            std::memcpy(N.box1, &box[2 * r + 1], 24);
+            N.ref0 = ref[2 * r];
+            N.ref1 = ref[2 * r + 1];
+            N.pad[0] = N.pad[1] = 0;
+        }
+        return me;
+    }
+
+    // Binary node over idx[b, e) (more than leaf_tris triangles); returns its node index.
     uint32_t build(uint32_t base, uint32_t b, uint32_t e, int depth_left) {
         const uint32_t me = (uint32_t)nodes.size();
         nodes.push_back(SubNode());
-        const uint32_t m = split(b, e, depth_left);
+        const uint32_t m = split(b, e, capacity(depth_left - 1, leaf_tris));
         const Box6 lb = range_box(b, m), rb = range_box(m, e);
-        uint32_t ref[2];
-        const uint32_t rb_[2] = {b, m}, re_[2] = {m, e};
-        for (int c = 0; c < 2; c++) {
-            const uint32_t cn = re_[c] - rb_[c];
-            // a child becomes a run of records when it is small enough or no depth is left
-            if (cn <= (uint32_t)leaf_tris || depth_left - 1 <= 0)
-                ref[c] = REF_LEAF | ((cn - 1) << 26) | (base + rb_[c]);
-            else
-                ref[c] = build(base, rb_[c], re_[c], depth_left - 1);
-        }
+        const uint32_t ref[2] = {child_ref(base, b, m, depth_left - 1), child_ref(base, m, e, depth_left - 1)};
         SubNode& N = nodes[me];
         std::memcpy(N.box0, &lb, 24);
         std::memcpy(N.box1, &rb, 24);
@@ -220,7 +265,7 @@ struct SubBuilder {
             }
             idx[i] = i;
         }
-        L.sub_root = build(L.first, 0, n, SUB_MAX_DEPTH);
+        L.sub_root = SUB_WIDTH == 4 ? build4(L.first, 0, n, SUB_MAX_DEPTH) : build(L.first, 0, n, SUB_MAX_DEPTH);
         leaf_tris = saved;
         // apply the permutation to the records (scan_k keeps every triangle's reference scan position)
         std::vector<TriRecord> t2(n);
@@ -421,6 +466,11 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         }
     if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
     // one 64-byte record array on the device: [packets | subnodes | tris]; make sub/tri references global
+    if (SUB_WIDTH == 4 && (out.packets.size() & 1u)) {
+        NodePacket pad;  // keeps every 128-byte accelerator node inside one 128-byte line (the array is 256-byte aligned)
+        std::memset(&pad, 0, sizeof(pad));
+        out.packets.push_back(pad);
+    }
     out.sub_base = (uint32_t)out.packets.size();
     out.tri_base = out.sub_base + (uint32_t)out.subnodes.size();
     if ((uint64_t)out.tri_base + out.tris.size() > SUB_MAX_RECORDS) {
@@ -434,7 +484,8 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         if (L.sub_root != REF_NONE) L.sub_root += out.sub_base;
     }
     for (SubNode& N : out.subnodes)
-        for (uint32_t* r : {&N.ref0, &N.ref1}) *r += (*r & REF_LEAF) ? out.tri_base : out.sub_base;
+        for (uint32_t* r : {&N.ref0, &N.ref1})
+            if (*r != REF_NONE) *r += (*r & REF_LEAF) ? out.tri_base : out.sub_base;
     out.root_box = out.nodes[0].box;
     out.root_ref = ref_of(0);
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

@@ -310,7 +310,7 @@ int64_t cgrt_leaf_prims(const CgrtScene* s, int node, uint32_t* out, uint32_t ca
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes) {
     if (node_bytes) *node_bytes = sizeof(NodePacket);
     if (tri_bytes) *tri_bytes = sizeof(TriRecord);
-    if (sub_bytes) *sub_bytes = sizeof(SubNode);
+    if (sub_bytes) *sub_bytes = sizeof(SubNode) * (SUB_WIDTH == 4 ? 2 : 1);  // bytes read per accelerator node visit
     if (hit_bytes) *hit_bytes = sizeof(CgrtHit);
 }
 

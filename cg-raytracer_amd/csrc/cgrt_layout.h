@@ -44,11 +44,18 @@ struct alignas(16) SubNode {
 static const uint32_t SUB_RUN_MAX = 32;            // records per run
 static const uint32_t SUB_MAX_RECORDS = 1u << 26;  // run references address records with 26 bits
 static_assert(sizeof(SubNode) == 64, "SubNode must be 64 B");
-#ifndef CGRT_SUB_MAX_DEPTH
-#define CGRT_SUB_MAX_DEPTH 8
+// Width of the in-leaf accelerator: 4 = every node is TWO consecutive SubNode records (four child boxes, half the
+// dependent steps of a binary tree; the frame is bounded by the dependent chain of its hardest rays), 2 = binary.
+#ifndef CGRT_SUB_WIDTH
+#define CGRT_SUB_WIDTH 4
 #endif
-static const int SUB_MAX_DEPTH = CGRT_SUB_MAX_DEPTH;  // per-ray sub-stack never exceeds this many entries
-static const int SUB_LEAF_TRIS = 3;    // target triangles per sub-leaf (1..4 measure within 2 %; 3 was best on the dragon frame)
+#ifndef CGRT_SUB_MAX_DEPTH
+#define CGRT_SUB_MAX_DEPTH (CGRT_SUB_WIDTH == 4 ? 5 : 8)
+#endif
+static const int SUB_WIDTH = CGRT_SUB_WIDTH;
+static const int SUB_MAX_DEPTH = CGRT_SUB_MAX_DEPTH;               // levels of the accelerator under one reference leaf
+static const int SUB_STACK_ENTRIES = (SUB_WIDTH - 1) * SUB_MAX_DEPTH;  // a step defers at most WIDTH-1 children
+static const int SUB_LEAF_TRIS = 2;    // target triangles per run (1..4 measure within 3 % of each other on the dragon frame)
 
 // One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent
 // trianglePlane (ray_tracing.cpp:74-82) evaluated once on the host with the reference's arithmetic.
