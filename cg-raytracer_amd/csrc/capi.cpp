@@ -478,9 +478,14 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
     NEED_DEVICE(s);
     if (W <= 0 || H <= 0 || max_level < 0 || max_level > 16) return fail(CGRT_E_ARG, "bad frame size or recursion depth");
     HIP_TRY(hipSetDevice(s->device));
-    const unsigned long long n = (unsigned long long)W * H;
+    const unsigned long long npix = (unsigned long long)W * H;
     const unsigned L = nlights;
-    DevBuf rays, nrays, hits, normals, srays, shits, sdist, dlights, levels, drgb, dstats;
+    CgrtRenderStats st{};
+    FrameDev F;
+    if (!make_frame(W, H, 0, 0, W, H, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame");
+    const unsigned long long n = (unsigned long long)F.nblocks * 256ull;  // items: the frame in the primary kernel's order
+    DevBuf rays, nrays, hits, normals, srays, shits, sdist, dlights, levels, drgb, dstats, ipix;
+    HIP_TRY(ipix.alloc(n * 4));
     HIP_TRY(rays.alloc(n * 28));
     HIP_TRY(nrays.alloc(n * 28));
     HIP_TRY(hits.alloc(n * sizeof(CgrtHit)));
@@ -490,13 +495,10 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
     HIP_TRY(sdist.alloc(n * L * 4));
     HIP_TRY(dlights.alloc((size_t)L * 24));
     HIP_TRY(levels.alloc((size_t)(max_level > 0 ? max_level : 1) * n * 32));
-    HIP_TRY(drgb.alloc(n * 12));
+    HIP_TRY(drgb.alloc(npix * 12));
     HIP_TRY(dstats.alloc(3 * sizeof(unsigned long long)));
     if (L) HIP_TRY(hipMemcpy(dlights.p, lights, (size_t)L * 24, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(dstats.p, 0, 3 * sizeof(unsigned long long)));
-    CgrtRenderStats st{};
-    FrameDev F;
-    if (!make_frame(W, H, 0, 0, W, H, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame");
     const CameraDev C = make_camera(*cam);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -504,9 +506,9 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
     HIP_TRY(hipEventRecord(e0, nullptr));
     int nlev = 0;
     if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
-        HIP_TRY(launch_generate_rays(C, W, H, 0, 0, W, H, rays.as<float>(), nullptr));
-        HIP_TRY(launch_trace_primary(s->dev, C, F, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
-        st.primary_rays = n;
+        HIP_TRY(launch_generate_rays_items(C, F, rays.as<float>(), ipix.as<int>(), nullptr));
+        HIP_TRY(launch_trace_batch(s->dev, rays.as<float>(), n, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
+        st.primary_rays = npix;
         float* cur = rays.as<float>();
         float* nxt = nrays.as<float>();
         for (int level = 0; level < max_level; level++) {
@@ -528,9 +530,9 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
         }
     }
     if (nlev == 0) {
-        HIP_TRY(hipMemset(drgb.p, 0, n * 12));
+        HIP_TRY(hipMemset(drgb.p, 0, npix * 12));
     } else {
-        HIP_TRY(launch_combine(levels.as<float>(), nlev, n, drgb.as<float>(), nullptr));
+        HIP_TRY(launch_combine(levels.as<float>(), nlev, n, ipix.as<int>(), drgb.as<float>(), nullptr));
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
@@ -540,7 +542,7 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
     (void)hipEventDestroy(e1);
     st.device_ms = ms;
     st.levels = nlev;
-    HIP_TRY(hipMemcpy(rgb, drgb.p, n * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rgb, drgb.p, npix * 12, hipMemcpyDeviceToHost));
     if (stats) *stats = st;
     return CGRT_OK;
 }

@@ -2,7 +2,8 @@
 // per recursion level one kernel spawns the shadow rays of every hit (pointInShadow, :104-135), the batch traversal
 // kernel answers them, one kernel evaluates the Phong terms (:61-98, :219-232) and spawns the mirror rays (shade,
 // :241-264), and after the last level one kernel folds the levels back (color = direct + reflected * ks, :262).
-// Paths are never compacted: item i of every level belongs to pixel i; dead paths carry a "null ray" that fails the
+// Paths are never compacted: item i of every level belongs to the same pixel (items are in the primary kernel's
+// frame order -- tiles, super-tiles -- so every batch stays tile-coherent); dead paths carry a "null ray" that fails the
 // root gate of the traversal at once.  Point lights only (spherical lights draw from std::random_device upstream).
 // Arithmetic follows the reference's expression order (cgrt_math.h); pow(float, float) is powf (device libm: the last
 // ulp may differ from glibc's -- the RGB parity bar is 1e-5 absolute).
@@ -126,9 +127,12 @@ __global__ void k_shade(const float* __restrict__ rays, const CgrtHitDev* __rest
 }
 
 // color_l = !hit ? 0 : (ks.z <= 0.01 ? direct : direct + color_{l+1} * ks)   (main.cpp:248, :262, :293)
-__global__ void k_combine(const float4* __restrict__ levels, int nlevels, unsigned long long n, float* __restrict__ rgb) {
+__global__ void k_combine(const float4* __restrict__ levels, int nlevels, unsigned long long n, const int* __restrict__ item_pixels,
+                          float* __restrict__ rgb) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const long long pix = item_pixels[i];
+    if (pix < 0) return;  // item outside the frame
     F3 below = f3(0.f, 0.f, 0.f);
     for (int l = nlevels - 1; l >= 0; l--) {
         const float4 a = levels[((unsigned long long)l * n + i) * 2], b = levels[((unsigned long long)l * n + i) * 2 + 1];
@@ -143,9 +147,9 @@ __global__ void k_combine(const float4* __restrict__ levels, int nlevels, unsign
         }
         below = c;
     }
-    rgb[3 * i] = below.x;
-    rgb[3 * i + 1] = below.y;
-    rgb[3 * i + 2] = below.z;
+    rgb[3 * pix] = below.x;
+    rgb[3 * pix + 1] = below.y;
+    rgb[3 * pix + 2] = below.z;
 }
 
 static inline unsigned grid_for(unsigned long long n, unsigned block) { return (unsigned)((n + block - 1) / block); }
@@ -163,8 +167,10 @@ hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* 
                            spawn, reinterpret_cast<float4*>(lvl), next_rays, stats);
     return hipGetLastError();
 }
-hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, float* rgb, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_combine, dim3(grid_for(n, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(levels), nlevels, n, rgb);
+hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s) {
+    if (n)
+        hipLaunchKernelGGL(k_combine, dim3(grid_for(n, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(levels), nlevels, n,
+                           item_pixels, rgb);
     return hipGetLastError();
 }
 

@@ -30,13 +30,15 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
                               unsigned long long* counters, hipStream_t stream);
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);
 
+// frame-ordered primary rays for the shading wavefront: n items = F.nblocks * 256; item_pixels[i] = y*W+x or -1
+hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, float* rays, int* item_pixels, hipStream_t stream);
 // shading wavefront (shade_kernels.hip)
 hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsigned long long n, const float* lights, unsigned nlights,
                                float* srays, float* sdist, hipStream_t s);
 hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
                         unsigned long long n, const float* materials, const float* lights, unsigned nlights, int spawn, float* lvl,
                         float* next_rays, unsigned long long* stats, hipStream_t s);
-hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, float* rgb, hipStream_t s);
+hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
 hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,
                                 hipStream_t s);
 hipError_t launch_ray_triangle(const float* tri, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, float* normals,

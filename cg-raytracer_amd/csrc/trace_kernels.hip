@@ -633,17 +633,22 @@ __device__ __forceinline__ void primary_ray(const CameraDev& C, int W, int H, in
 // Workgroup -> super-tile -> tile -> pixel (FrameDev in cgrt_layout.h): blockIdx % 8 selects the XCD lane of
 // the rank's super-tile list, 16 consecutive workgroups of that lane cover one 64x64 super-tile, the 4 waves
 // of a workgroup take 4 horizontally adjacent 8x8 tiles.
-__device__ __forceinline__ bool tile_pixel(const FrameDev& F, int lane, int& x, int& y) {
-    const uint32_t b = blockIdx.x, lane8 = b & 7u, j = b >> 3;
+__device__ __forceinline__ bool tile_pixel_of(const FrameDev& F, const uint32_t b, const uint32_t tid, int& x, int& y) {
+    const uint32_t lane8 = b & 7u, j = b >> 3;
+    const int lane = (int)(tid & 63u);
     const uint32_t s = (j >> 4) * 8u + lane8;  // rank-local super-tile
     if (s >= F.nst_rank) return false;
     const uint32_t st = (uint32_t)F.rank + (uint32_t)F.nranks * s;
     const int stx = (int)(st % (uint32_t)F.st_x), sty = (int)(st / (uint32_t)F.st_x);
-    const int idx = (int)(j & 15u) * 4 + (int)(threadIdx.x >> 6);
+    const int idx = (int)(j & 15u) * 4 + (int)(tid >> 6);
     const int tx = stx * ST_TILES + (idx & 7), ty = sty * ST_TILES + (idx >> 3);
     x = F.x0 + tx * 8 + (lane & 7);
     y = F.y0 + ty * 8 + (lane >> 3);
     return x < F.x1 && y < F.y1;
+}
+__device__ __forceinline__ bool tile_pixel(const FrameDev& F, int lane, int& x, int& y) {
+    (void)lane;
+    return tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y);
 }
 
 // STAMP (diagnostic build only, never timed): lane 0 of every wave writes {start, end} of s_memtime and
@@ -874,6 +879,37 @@ __global__ __launch_bounds__(CGRT_BLOCK) void k_generate_rays(CameraDev C, int W
     r[6] = 3.402823466e+38f;
 }
 
+// Primary rays in FRAME ORDER (item i = workgroup i / 256 of the primary kernel's decomposition, thread i % 256): the
+// shading wavefront keeps this order for every batch it sends through k_trace_batch, so its secondary rays inherit the
+// tile coherence and the XCD locality of the primary frame.  Items outside the frame get a ray that fails the root gate.
+__global__ __launch_bounds__(CGRT_BLOCK) void k_generate_rays_items(CameraDev C, FrameDev F, float* __restrict__ rays) {
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    int x = 0, y = 0;
+    float* r = rays + 7ull * ((unsigned long long)b * CGRT_BLOCK + tid);
+    if (tile_pixel_of(F, b, tid, x, y)) {
+        F3 o, d;
+        primary_ray(C, F.W, F.H, x, y, o, d);
+        r[0] = o.x;
+        r[1] = o.y;
+        r[2] = o.z;
+        r[3] = d.x;
+        r[4] = d.y;
+        r[5] = d.z;
+        r[6] = 3.402823466e+38f;
+    } else {
+        r[0] = r[1] = r[2] = 3.402823466e+38f;
+        r[3] = 1.0f;
+        r[4] = r[5] = 0.0f;
+        r[6] = 0.0f;
+    }
+}
+// item -> pixel index (y*W + x), or -1 for items outside the frame
+__global__ __launch_bounds__(CGRT_BLOCK) void k_item_pixels(FrameDev F, int* __restrict__ pix) {
+    int x = 0, y = 0;
+    const bool in = tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y);
+    pix[(unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x] = in ? y * F.W + x : -1;
+}
+
 // ---- element-wise primitives (src/ray_tracing.h:10-20) ----
 __global__ void k_ray_triangle(const float* __restrict__ tri, const float* __restrict__ rays, unsigned long long n,
                                float* __restrict__ t_out, uint8_t* __restrict__ hit, float* __restrict__ normals) {
@@ -1025,6 +1061,12 @@ hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0
     const unsigned long long n = (unsigned long long)(x1 - x0) * (unsigned long long)(y1 - y0);
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_generate_rays, dim3(grid_for(n, CGRT_BLOCK)), dim3(CGRT_BLOCK), 0, stream, C, W, H, x0, y0, x1, y1, rays);
+    return hipGetLastError();
+}
+hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, float* rays, int* item_pixels, hipStream_t stream) {
+    if (F.nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_generate_rays_items, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, C, F, rays);
+    hipLaunchKernelGGL(k_item_pixels, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, F, item_pixels);
     return hipGetLastError();
 }
 hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,
