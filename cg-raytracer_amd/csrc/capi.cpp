@@ -634,6 +634,32 @@ int cgrt_ray_sphere_batch(int device, const float* sphere, const CgrtRay* rays, 
     return CGRT_OK;
 }
 
+int cgrt_debug_gather_calibration(int device, uint64_t nrecords, int repeats) {
+    // nrecords x 64 B of zeros, each record read exactly once per launch in a scattered order (see k_gather_calib)
+    int n_ = 1;
+    (void)n_;
+    int rc_ = select_device(device);
+    if (rc_) return rc_;
+    if (nrecords < 1024 || repeats < 1) return fail(CGRT_E_ARG, "nrecords >= 1024, repeats >= 1");
+    DevBuf table, sink;
+    HIP_TRY(table.alloc((size_t)nrecords * 64));
+    HIP_TRY(sink.alloc(16));
+    HIP_TRY(hipMemset(table.p, 0, (size_t)nrecords * 64));
+    unsigned long long mult = 2654435761ull;
+    auto gcd = [](unsigned long long a, unsigned long long b) {
+        while (b) {
+            const unsigned long long t = a % b;
+            a = b;
+            b = t;
+        }
+        return a;
+    };
+    while (gcd(mult, nrecords) != 1) mult += 2;
+    for (int r = 0; r < repeats; r++) HIP_TRY(launch_gather_calib(table.p, nrecords, mult, 12345ull + 7919ull * r, sink.as<float>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return CGRT_OK;
+}
+
 int cgrt_debug_fastdiv_check(int device, const float* a, const float* d, uint64_t n, uint64_t* mismatches, float* first_bad) {
     if (n && (!a || !d || !mismatches || !first_bad)) return fail(CGRT_E_ARG, "NULL argument");
     PRIM_PROLOGUE(device)

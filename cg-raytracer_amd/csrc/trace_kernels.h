@@ -39,6 +39,8 @@ hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* 
                         unsigned long long n, const float* materials, const float* lights, unsigned nlights, int spawn, float* lvl,
                         float* next_rays, unsigned long long* stats, hipStream_t s);
 hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
+hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
+                               hipStream_t s);
 hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,
                                 hipStream_t s);
 hipError_t launch_ray_triangle(const float* tri, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, float* normals,

@@ -988,6 +988,19 @@ __global__ void k_point_in_triangle(const float* __restrict__ in, unsigned long 
     out[i] = point_in_triangle(ld3(q), ld3(q + 3), ld3(q + 6), ld3(q + 9), ld3(q + 12));
 }
 
+// calibration kernel for the FETCH_SIZE counter: every lane reads ONE 64-byte record (4 x dwordx4, the access shape of
+// the traversal kernels) at a pseudo-random, never repeated position of a table far larger than the Infinity Cache.
+__global__ void k_gather_calib(const float4* __restrict__ table, unsigned long long nrecords, unsigned long long mult,
+                               unsigned long long add, float* __restrict__ sink) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrecords) return;
+    const unsigned long long j = (i * mult + add) % nrecords;  // mult coprime with nrecords: a permutation
+    const float4* q = table + 4 * j;
+    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    const float v = a.x + b.y + c.z + e.w;
+    if (v == 123456.0f) sink[0] = v;  // keeps the loads alive
+}
+
 // diagnostic / test kernel: fdiv4 against IEEE a / d, bit for bit (zeros compare equal regardless of sign)
 __global__ void k_fastdiv_check(const float* __restrict__ a, const float* __restrict__ d, unsigned long long n,
                                 unsigned long long* __restrict__ mismatches, float* __restrict__ first_bad) {
@@ -1067,6 +1080,13 @@ hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, flo
     if (F.nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_generate_rays_items, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, C, F, rays);
     hipLaunchKernelGGL(k_item_pixels, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, F, item_pixels);
+    return hipGetLastError();
+}
+hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
+                               hipStream_t s) {
+    if (nrecords)
+        hipLaunchKernelGGL(k_gather_calib, dim3(grid_for(nrecords, 256)), dim3(256), 0, s, static_cast<const float4*>(table), nrecords, mult,
+                           add, sink);
     return hipGetLastError();
 }
 hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,

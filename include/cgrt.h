@@ -153,6 +153,10 @@ int cgrt_count_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, CgrtCoun
  * wave-level iterations of the inner, sub-node and triangle bodies; per-lane maxima of inner/leaf/tri/sub; active
  * lanes.  One record per launched wave: cap_waves >= 4 * 16 * 8 * ceil(ceil(W/64)*ceil(H/64) / 8). */
 int cgrt_debug_wave_times(CgrtScene* scene, const CgrtCamera* cam, int W, int H, uint64_t* out, uint64_t cap_waves);
+/* Diagnostic: `repeats` launches of a kernel that reads nrecords scattered 64-byte records (one per lane, never twice)
+ * from a zeroed table -- a known HBM byte count in the traversal kernels' access shape, for calibrating rocprofv3's
+ * FETCH_SIZE on gfx950 (tools/calibrate_fetch_size.sh). */
+int cgrt_debug_gather_calibration(int device, uint64_t nrecords, int repeats);
 /* Diagnostic: the kernels' 4-operation exact division (trace_kernels.hip fdiv4) against IEEE a[i] / d[i] on the
  * device; mismatches receives the count, first_bad {a, d, got, expected} of the first one. */
 int cgrt_debug_fastdiv_check(int device, const float* a, const float* d, uint64_t n, uint64_t* mismatches, float* first_bad);

@@ -23,12 +23,13 @@ def mean(path, kernel="k_trace_primary<false"):
 res={}
 for n in ("fetch","write","cache","sq"): res.update(mean(f"{out}/{n}/p_counter_collection.csv"))
 bench=json.loads(open(f"{out}/bench_under_trace.json").read())
-# FETCH_SIZE/WRITE_SIZE are in KiB-ish units of 1 KB (rocprofv3 derives them from TCC_EA0_RDREQ*64B / WRREQ); on gfx950
-# FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section): the x2 correction is the UPPER bound
-# for this kernel's 16-B-per-lane gathers, so both figures are kept.
+# FETCH_SIZE/WRITE_SIZE are in units of 1 KB (rocprofv3 derives them from TCC_EA0_RDREQ*64B / WRREQ).  On gfx950 FETCH_SIZE
+# reads 1/2 of a WIDE COALESCED stream (MI355X_MICROARCH.md HBM section) and is uncalibrated for other shapes; for this
+# kernel's shape -- scattered 64-byte records, 16 B per lane per instruction -- tools/calibrate_fetch_size.sh measured
+# counter/known-bytes = 1.0000 on a 1 GiB table (profiles/r1_fetch_size_calibration.txt), so the raw value is used.
 fetch_b = res.get("FETCH_SIZE",0)*1024; write_b = res.get("WRITE_SIZE",0)*1024
 summary = {"counters": res, "fetch_bytes_raw": fetch_b, "fetch_bytes_x2_gfx950": 2*fetch_b, "write_bytes": write_b,
-           "hbm_bytes_per_launch": 2*fetch_b + write_b,
+           "hbm_bytes_per_launch": fetch_b + write_b,
            "workload": "dragon%s_%s" % (re.search(r"stand-in (\d+) tris", bench["config"]["workload"]).group(1), re.search(r"(\d+x\d+) primary", bench["config"]["workload"]).group(1)),
            "bench_under_trace": {k: bench[k] for k in ("value","ms_per_step")}, "roofline": bench["roofline"]}
 json.dump(summary, open(f"{out}/summary.json","w"), indent=1)
