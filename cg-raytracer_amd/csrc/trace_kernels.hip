@@ -10,8 +10,8 @@
 // ray.t only changes when a triangle is accepted.  A child whose box test failed (t = -1) is dropped,
 // and an origin strictly inside both child boxes visits both unconditionally (:685-688).
 // Inside a reference leaf the linear scan of intersectLeaf (bvh.cpp:535-553) is replaced by an order-free
-// but outcome-identical evaluation over a per-leaf binary BVH (scan_leaf below, DESIGN.md "In-leaf accelerator").
-// The per-lane stack (<= 11 deferred children, bvh.cpp:48, plus <= 12 in-leaf entries) lives in LDS,
+// but outcome-identical evaluation over a per-leaf 4-wide BVH (scan_leaf below, DESIGN.md "In-leaf accelerator").
+// The per-lane stack (<= 11 deferred children, bvh.cpp:48, plus <= 15 in-leaf entries) lives in LDS,
 // lane-interleaved so that every access is bank-conflict free; runtime-indexed register arrays would go
 // to scratch.
 //
@@ -30,10 +30,6 @@ namespace cgrt {
 
 #define CGRT_BLOCK 256
 // ---- experiment knobs (build variants with -D...; defaults are the shipped configuration) ----
-#ifndef CGRT_SUB_TN
-#define CGRT_SUB_TN 0  // 1: in-leaf stack entries also carry their entry parameter and are culled on pop (measured: no gain,
-                       // +32 B of LDS per lane)
-#endif
 #ifndef CGRT_MIN_WAVES
 #define CGRT_MIN_WAVES 0  // __launch_bounds__ second argument (waves per SIMD) for the trace kernels, 0 = unset
 #endif
@@ -46,10 +42,9 @@ namespace cgrt {
 #else
 #define CGRT_LB __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(1, CGRT_MAX_WAVES)))
 #endif
-#define CGRT_SUB_SLOTS (CGRT_SUB_TN ? 2 : 1)
 // Per-lane LDS stack, in 4-byte slots: a deferred reference child takes 2 slots (ref, tSecond), at most
 // MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 1 slot (ref), at most SUB_STACK_ENTRIES.
-#define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + CGRT_SUB_SLOTS * SUB_STACK_ENTRIES)
+#define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES)
 
 #ifndef CGRT_STAMP_SUB
 #define CGRT_STAMP_SUB 0  // diagnostic build: in-loop s_memtime stamps of the accelerator node step (load wait vs compute)
@@ -190,8 +185,7 @@ __device__ __forceinline__ uint32_t run_count(const uint32_t r) { return ((r >> 
 
 // intersectLeaf (bvh.cpp:535-553) for one ray.  "while-while": lanes first step through accelerator nodes
 // until each stands on a run of triangles (or has nothing left), then the runs are tested together.
-// Stack entries are {ref, conservative entry parameter}: an entry is dropped on pop when the scan's
-// running minimum has moved in front of it.
+// Stack entries are bare references (carrying the entry parameter for culling on pop was measured: no gain).
 template <bool COUNT>
 __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, const F3 o, const F3 d, const RayPre& P, float& t,
                                           uint32_t& hit_rec, uint32_t* __restrict__ stk, const int sp0, LaneCounters& cnt) {
@@ -300,10 +294,7 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
                 const uint32_t rn = swap ? m.y : m.x, rf = swap ? m.x : m.y;
                 if (h0 && h1) {
                     stk[sp * CGRT_BLOCK] = rf;
-#if CGRT_SUB_TN
-                    stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(swap ? tn0 : tn1);
-#endif
-                    sp += CGRT_SUB_SLOTS;
+                    sp += 1;
                 }
                 cur = (h0 || h1) ? rn : REF_NONE;
 #if CGRT_STAMP_SUB
@@ -326,21 +317,10 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
 #endif
             // ---- pop ----
             cur = REF_NONE;
-#if CGRT_SUB_TN
-            while (sp > sp0) {
-                sp -= 2;
-                const float tn = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
-                if (tn <= fmaxf(L.best_t, 0.0f)) {
-                    cur = stk[sp * CGRT_BLOCK];
-                    break;
-                }
-            }
-#else
             if (sp > sp0) {
                 sp -= 1;
                 cur = stk[sp * CGRT_BLOCK];
             }
-#endif
             if (cur == REF_NONE) break;
         }
     }

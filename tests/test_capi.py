@@ -76,3 +76,23 @@ def test_product_does_not_reference_the_oracle(pkg):
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "cgrt_oracle" not in txt and "oracle/" not in txt, f"{f} mentions the oracle"
+
+
+def test_option_setters_validate(pkg):
+    L = pkg.lib()
+    assert L.cgrt_set_primary_mode(2) == -1 and b"mode" in L.cgrt_last_error()
+    assert L.cgrt_set_primary_mode(0) == 0
+    assert L.cgrt_set_leaf_accel(1, 65) == -1
+    assert L.cgrt_set_leaf_accel(1, 0) == 0
+
+
+def test_render_rejects_bad_arguments(pkg, scene_data):
+    s = pkg.Scene(scene_data("cube"), device=-1)
+    import ctypes as C
+
+    cam = pkg.Camera.from_array(pkg.scenes.default_camera(8, 8))
+    rgb = np.zeros(8 * 8 * 3, np.float32)
+    rc = pkg.lib().cgrt_render(s._h, C.byref(cam), 8, 8, None, 0, 2, rgb.ctypes.data_as(C.c_void_p), None)
+    assert rc == -2  # host-only scene: no CPU shading/traversal path either
+    rc = pkg.lib().cgrt_render(s._h, C.byref(cam), 8, 8, None, 3, 2, rgb.ctypes.data_as(C.c_void_p), None)
+    assert rc == -1  # lights missing
