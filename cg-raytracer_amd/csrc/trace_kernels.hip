@@ -200,33 +200,33 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
     } else if (SUB_WIDTH == 4) {
         int sp = sp0;
         uint32_t cur = LR.sub_root;
-        for (;;) {
-            // ---- node phase: one 128-byte node = four child boxes ----
-            while (cur != REF_NONE && !(cur & REF_LEAF)) {
-                if (COUNT) {
-                    cnt.sub++;
-                    if (first_active_lane()) cnt.w_sub++;
-                }
-                const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
-                const float4 a0 = q[0], b0 = q[1], c0 = q[2];
-                const uint2 m0 = *reinterpret_cast<const uint2*>(q + 3);
-                const float4 a1 = q[4], b1 = q[5], c1 = q[6];
-                const uint2 m1 = *reinterpret_cast<const uint2*>(q + 7);
-                float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
-                slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
-                slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);
-                slab_cons(P, f3(a1.x, a1.y, a1.z), f3(a1.w, b1.x, b1.y), tn2, tf2);
-                slab_cons(P, f3(b1.z, b1.w, c1.x), f3(c1.y, c1.z, c1.w), tn3, tf3);
-                // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
-                // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
-                const float tc = fmaxf(L.best_t, 0.0f);
-                const float inf = __builtin_inff();
-                // sort key: entry parameter of a hit child, +inf for a missed (or absent: empty box) one
-                float k0 = ((tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc)) ? tn0 : inf;
-                float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
-                float k2 = ((tn2 <= tf2) && (tf2 >= 0.0f) && (tn2 <= tc)) ? tn2 : inf;
-                float k3 = ((tn3 <= tf3) && (tf3 >= 0.0f) && (tn3 <= tc)) ? tn3 : inf;
-                uint32_t r0 = m0.x, r1 = m0.y, r2 = m1.x, r3 = m1.y;
+        // One step through a 128-byte node (four child boxes): the nearest hit child becomes `cur`, the other hit
+        // children are deferred far-to-near so that they pop near-to-far.
+        auto node_step = [&]() __attribute__((always_inline)) {
+            if (COUNT) {
+                cnt.sub++;
+                if (first_active_lane()) cnt.w_sub++;
+            }
+            const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
+            const float4 a0 = q[0], b0 = q[1], c0 = q[2];
+            const uint2 m0 = *reinterpret_cast<const uint2*>(q + 3);
+            const float4 a1 = q[4], b1 = q[5], c1 = q[6];
+            const uint2 m1 = *reinterpret_cast<const uint2*>(q + 7);
+            float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
+            slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
+            slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);
+            slab_cons(P, f3(a1.x, a1.y, a1.z), f3(a1.w, b1.x, b1.y), tn2, tf2);
+            slab_cons(P, f3(b1.z, b1.w, c1.x), f3(c1.y, c1.z, c1.w), tn3, tf3);
+            // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
+            // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
+            const float tc = fmaxf(L.best_t, 0.0f);
+            const float inf = __builtin_inff();
+            // sort key: entry parameter of a hit child, +inf for a missed (or absent: empty box) one
+            float k0 = ((tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc)) ? tn0 : inf;
+            float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
+            float k2 = ((tn2 <= tf2) && (tf2 >= 0.0f) && (tn2 <= tc)) ? tn2 : inf;
+            float k3 = ((tn3 <= tf3) && (tf3 >= 0.0f) && (tn3 <= tc)) ? tn3 : inf;
+            uint32_t r0 = m0.x, r1 = m0.y, r2 = m1.x, r3 = m1.y;
 #define CGRT_CSWAP(ka, ra, kb, rb)          \
     {                                       \
         const bool sw = kb < ka;            \
@@ -237,23 +237,25 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
         ka = kt;                            \
         ra = rt;                            \
     }
-                CGRT_CSWAP(k0, r0, k1, r1)
-                CGRT_CSWAP(k2, r2, k3, r3)
-                CGRT_CSWAP(k0, r0, k2, r2)
-                CGRT_CSWAP(k1, r1, k3, r3)
-                CGRT_CSWAP(k1, r1, k2, r2)
+            CGRT_CSWAP(k0, r0, k1, r1)
+            CGRT_CSWAP(k2, r2, k3, r3)
+            CGRT_CSWAP(k0, r0, k2, r2)
+            CGRT_CSWAP(k1, r1, k3, r3)
+            CGRT_CSWAP(k1, r1, k2, r2)
 #undef CGRT_CSWAP
-                // nearest first; the others are deferred far-to-near so that they pop near-to-far.  Branch-free: the
-                // slot is always written and only kept (sp advanced) when the child was hit; a level defers at most
-                // three children, so the writes stay inside the lane's SUB_STACK_ENTRIES slots.
-                stk[sp * CGRT_BLOCK] = r3;
-                sp += (k3 < inf) ? 1 : 0;
-                stk[sp * CGRT_BLOCK] = r2;
-                sp += (k2 < inf) ? 1 : 0;
-                stk[sp * CGRT_BLOCK] = r1;
-                sp += (k1 < inf) ? 1 : 0;
-                cur = (k0 < inf) ? r0 : REF_NONE;
-            }
+            // Branch-free pushes: the slot is always written and only kept (sp advanced) when the child was hit; a
+            // level defers at most three children, so the writes stay inside the lane's SUB_STACK_ENTRIES slots.
+            stk[sp * CGRT_BLOCK] = r3;
+            sp += (k3 < inf) ? 1 : 0;
+            stk[sp * CGRT_BLOCK] = r2;
+            sp += (k2 < inf) ? 1 : 0;
+            stk[sp * CGRT_BLOCK] = r1;
+            sp += (k1 < inf) ? 1 : 0;
+            cur = (k0 < inf) ? r0 : REF_NONE;
+        };
+        for (;;) {
+            // ---- node phase ----
+            while (cur != REF_NONE && !(cur & REF_LEAF)) node_step();
             // ---- triangle phase ----
             if (cur != REF_NONE) test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, L, cnt);
             // ---- pop ----
