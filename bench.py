@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="independent frames kept in flight on separate HIP streams (1 = strictly back to back, the reported default)")
     args = ap.parse_args()
 
     import torch
@@ -119,11 +121,18 @@ def main():
     scene = pkg.Scene(sd, device=local_rank)
     setup_s = time.time() - t0
 
-    hits = torch.empty(W * H * 4, dtype=torch.int32, device="cuda")  # CgrtHit x W*H, resident in HBM
-    stream = torch.cuda.current_stream().cuda_stream
+    nfl = max(1, args.frames_in_flight)
+    hits_bufs = [torch.empty(W * H * 4, dtype=torch.int32, device="cuda") for _ in range(nfl)]  # CgrtHit x W*H each, in HBM
+    hits = hits_bufs[0]
+    main_stream = torch.cuda.current_stream()
+    streams = [main_stream] + [torch.cuda.Stream() for _ in range(nfl - 1)]
+    stream = main_stream.cuda_stream
+    step_no = [0]
 
     def step():
-        scene.trace_primary_device(cam, W, H, hits.data_ptr(), rank=rank, nranks=world, stream=stream)
+        k = step_no[0] % nfl
+        step_no[0] += 1
+        scene.trace_primary_device(cam, W, H, hits_bufs[k].data_ptr(), rank=rank, nranks=world, stream=streams[k].cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -139,6 +148,8 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         step()
+    for st in streams[1:]:
+        main_stream.wait_stream(st)  # the closing event covers every frame in flight
     ev1.record()
     barrier()
     wall = time.perf_counter() - t_start
@@ -176,6 +187,7 @@ def main():
                 "workload": f"dragon stand-in {sd.ntris} tris (1 mesh, 12-level reference BVH), {W}x{H} primary rays, "
                             f"reference default camera, 8x8 tiles interleaved over {world} rank(s)",
                 "rays_per_step": total_rays,
+                "frames_in_flight": nfl,
                 "rays_rank0": my_rays,
                 "bvh_build_and_upload_s": round(setup_s, 3),
                 "scene_device_MB": round(scene.device_bytes() / 1e6, 1),
