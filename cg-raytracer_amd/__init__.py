@@ -107,7 +107,10 @@ def lib() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        try:  # not shipped with this checkout: compile it now (hipcc, gfx950); there is no other path to fall back to
+            build_native()
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError(f"{LIB_PATH} is missing and could not be built: {e}") from e
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.cgrt_last_error.restype = C.c_char_p
