@@ -403,6 +403,7 @@ def host_lib() -> C.CDLL:
         H.cgrt_host_render.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, vp, vp]
         H.cgrt_host_load_obj.argtypes = [C.c_char_p, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp]
         H.cgrt_host_write_bmp.argtypes = [C.c_char_p, vp, i32, i32]
+        H.cgrt_host_selftest.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, C.POINTER(i32)]
         _host = H
     return _host
 
@@ -434,6 +435,20 @@ def host_load_obj(path: str, normalize: bool = False) -> SceneData:
     mats = np.zeros((nm.value, 8), np.float32)
     Hl.cgrt_host_load_obj(path.encode(), int(normalize), C.byref(nv), C.byref(nt), C.byref(nm), _ptr(pn), _ptr(tri), _ptr(tm), _ptr(mats))
     return SceneData(pos_nrm=pn, tri=tri, tri_mesh=tm, materials=mats)
+
+
+def host_selftest(sd: SceneData, rays7) -> Tuple[int, int]:
+    """Runs the C++ mirror's per-ray API (BoundingVolumeHierarchy::intersect, free functions, copy-assign) against its
+    batched API on the given rays. Returns (disagreements, numLevels)."""
+    Hl = host_lib()
+    pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+    tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
+    r = _f32(rays7, (-1, 7))
+    lv = C.c_int(0)
+    bad = Hl.cgrt_host_selftest(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(r), len(r), C.byref(lv))
+    if bad < 0:
+        raise RuntimeError("cgrt_host_selftest: " + Hl.cgrt_host_last_error().decode())
+    return int(bad), int(lv.value)
 
 
 def host_write_bmp(path: str, rgb, W: int, H: int) -> None:

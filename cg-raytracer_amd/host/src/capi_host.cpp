@@ -110,6 +110,94 @@ int cgrt_host_load_obj(const char* path, int normalize, uint32_t* nverts, uint32
     }
 }
 
+// Exercises the drop-in C++ surface the way reference code uses it (main.cpp:276, :115, :776-777): per-ray
+// BoundingVolumeHierarchy::intersect(Ray&, HitInfo&), copy-assignment of a freshly built BVH, numLevels(), and the
+// free functions of ray_tracing.h, and checks them against the batched entry on the same rays.  rays: n x 7 floats.
+// Returns the number of disagreements (0 = pass), -1 on an exception.
+int cgrt_host_selftest(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
+                       const float* materials, uint32_t nmesh, const float* rays7, uint32_t nrays, int* levels_out) {
+    try {
+        Scene sc = scene_from_arrays(pos_nrm, nverts, tri, tri_mesh, ntris, materials, nmesh, nullptr, 0);
+        BoundingVolumeHierarchy bvh(&sc);
+        {
+            Scene empty;
+            BoundingVolumeHierarchy other(&empty);
+            other = BoundingVolumeHierarchy(&sc);  // main.cpp:776-777
+            bvh = other;
+        }
+        if (levels_out) *levels_out = bvh.numLevels();
+        bvh.debugDraw(0);
+        std::vector<Ray> rays(nrays);
+        for (uint32_t i = 0; i < nrays; i++) {
+            const float* p = rays7 + 7 * i;
+            rays[i].origin = cgrt::vec3(p[0], p[1], p[2]);
+            rays[i].direction = cgrt::vec3(p[3], p[4], p[5]);
+            rays[i].t = p[6];
+        }
+        std::vector<Ray> batch = rays;
+        std::vector<HitInfo> bhi(nrays);
+        std::vector<uint8_t> bhit(nrays);
+        for (auto& h : bhi) {
+            h.normal = cgrt::vec3(7.0f, 8.0f, 9.0f);
+            h.material.shininess = -3.0f;
+        }
+        bvh.intersectBatch(batch.data(), bhi.data(), bhit.data(), nrays);
+        int bad = 0;
+        for (uint32_t i = 0; i < nrays; i++) {
+            Ray r = rays[i];
+            HitInfo hi;
+            hi.normal = cgrt::vec3(7.0f, 8.0f, 9.0f);
+            hi.material.shininess = -3.0f;
+            const bool hit = bvh.intersect(r, hi);  // one ray at a time, as the reference calls it
+            bad += hit != (bhit[i] != 0);
+            bad += std::memcmp(&r.t, &batch[i].t, 4) != 0;
+            bad += std::memcmp(&hi.normal, &bhi[i].normal, 12) != 0;
+            bad += std::memcmp(&hi.material, &bhi[i].material, sizeof(Material)) != 0;
+            if (!hit) bad += !(hi.normal.x == 7.0f && hi.material.shininess == -3.0f);  // HitInfo untouched on a miss
+        }
+        // free functions on the first triangle of the scene against the same ray through the Mesh overload
+        if (!sc.meshes.empty() && !sc.meshes[0].triangles.empty() && nrays > 0) {
+            const Mesh& m = sc.meshes[0];
+            const Triangle& t = m.triangles[0];
+            const Vertex &v0 = m.vertices[t[0]], &v1 = m.vertices[t[1]], &v2 = m.vertices[t[2]];
+            const Plane pl = trianglePlane(v0.p, v1.p, v2.p);
+            for (uint32_t i = 0; i < nrays && i < 64; i++) {
+                Ray a = rays[i], b = rays[i];
+                HitInfo ha, hb;
+                const bool h1 = intersectRayWithTriangle(v0.p, v1.p, v2.p, a, ha, v0.n, v1.n, v2.n);
+                bool h2 = false;
+                const float prev = b.t;
+                if (intersectRayWithPlane(pl, b)) {
+                    if (pointInTriangle(v0.p, v1.p, v2.p, pl.normal, b.origin + b.direction * b.t))
+                        h2 = true;
+                    else
+                        b.t = prev;
+                }
+                bad += h1 != h2;
+                bad += std::memcmp(&a.t, &b.t, 4) != 0;
+                Mesh one;
+                one.vertices = {v0, v1, v2};
+                one.triangles = {Triangle(0, 1, 2)};
+                Ray c = rays[i];
+                HitInfo hc;
+                bad += intersectRayWithShape(one, c, hc) != h1;
+                bad += std::memcmp(&c.t, &a.t, 4) != 0;
+                AxisAlignedBox box{cgrt::vec3(-0.5f), cgrt::vec3(0.5f)};
+                Ray e = rays[i];
+                (void)intersectRayWithShape(box, e);
+                Sphere sp{cgrt::vec3(0.0f), 0.5f, Material{}};
+                Ray f = rays[i];
+                HitInfo hf;
+                (void)intersectRayWithShape(sp, f, hf);
+            }
+        }
+        return bad;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // Writes rgb (W*H*3 floats, index y*W+x, y up) through Screen::setPixel + writeBitmapToFile.
 int cgrt_host_write_bmp(const char* path, const float* rgb, int W, int H) {
     try {

@@ -99,3 +99,18 @@ def test_config3_device_render_1080p_depth4(pkg, orc, scene_data):
     ref, nrays = orc.OracleScene(sd).render(cam, W, H, sd.point_lights, max_level=4)
     assert np.abs(rgb.astype(np.float64) - ref).max() <= 1e-5
     assert st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"] == nrays and st["levels"] >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cube", "monkey"])
+def test_cpp_per_ray_api_equals_batch(pkg, orc, scene_data, name):
+    """The drop-in surface used the reference's way: BoundingVolumeHierarchy::intersect(Ray&, HitInfo&) one ray at a
+    time, copy-assignment of the BVH (main.cpp:776-777), numLevels(), debugDraw(), intersectRayWith* / pointInTriangle
+    / trianglePlane -- all agree bit for bit with the batched entry, and HitInfo is untouched on a miss."""
+    sd = scene_data(name)
+    W = H = 24
+    rays = orc.generate_rays(pkg.scenes.default_camera(W, H), W, H)
+    rays[::5, 6] = 2.5  # finite ray.t on some
+    bad, levels = pkg.host_selftest(sd, rays)
+    assert bad == 0
+    assert levels == orc.OracleScene(sd).num_levels()
