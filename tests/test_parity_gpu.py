@@ -238,6 +238,36 @@ def test_random_multi_mesh_scenes_with_degenerates(pkg, orc, seed):
     assert hits["hit"].mean() > 0.1
 
 
+@pytest.mark.parametrize("name", ["monkey", "blob"])
+def test_non_finite_rays(pkg, orc, scene_data, name):
+    """NaN / +-inf in origin, direction or ray.t: every comparison with a NaN is false on both sides, the walk must
+    terminate and agree with the oracle (t compared NaN-aware)."""
+    sd = scene_data(name)
+    rng = np.random.RandomState(31)
+    n = 6000
+    rays = np.zeros((n, 7), np.float32)
+    rays[:, 0:3] = rng.uniform(-2, 2, (n, 3))
+    d = rng.uniform(-0.5, 0.5, (n, 3)) - rays[:, 0:3]
+    rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 6] = FMAX
+    special = np.float32([np.nan, np.inf, -np.inf])
+    for i in range(n):
+        k = i % 8
+        if k < 7:
+            rays[i, k] = special[(i // 8) % 3]
+        else:  # two poisoned components
+            rays[i, rng.randint(0, 3)] = np.nan
+            rays[i, 3 + rng.randint(0, 3)] = np.inf
+    o = orc.OracleScene(sd)
+    ref = o.intersect(rays)
+    hits, normals = pkg.Scene(sd).intersect(_rays(pkg, rays))
+    assert np.array_equal(hits["hit"], ref["hit"])
+    assert same_bits(hits["t"], ref["t"]).all()
+    assert np.array_equal(hits["prim_id"], ref["prim"]) and np.array_equal(hits["material_id"], ref["material"])
+    m = ref["hit"] == 1
+    assert same_bits(normals[m], ref["normal"][m]).all()
+
+
 def test_f4_false_misses_reproduced_on_gpu(pkg, scene_data):
     sc = pkg.Scene(scene_data("cube"))
     rays = pkg.as_rays(np.broadcast_to(np.float32(rayfam.F4_ORIGIN), (3, 3)), np.float32(rayfam.F4_DIRS))
