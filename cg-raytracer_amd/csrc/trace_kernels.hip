@@ -46,6 +46,13 @@ namespace cgrt {
 // MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 1 slot (ref), at most SUB_STACK_ENTRIES.
 #define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES)
 
+#ifndef CGRT_QUAD
+#define CGRT_QUAD 0  // 1: lane-cooperative leaf scans for waves with few live rays (scan_leaves_quad).  Bit-identical results;
+                     // measured: slowest wave -10 %, but 154 VGPRs drop the kernel to 3 waves per SIMD and the frame gets 4 % slower
+#endif
+#ifndef CGRT_QUAD_MAX_RAYS
+#define CGRT_QUAD_MAX_RAYS 16
+#endif
 #ifndef CGRT_STAMP_SUB
 #define CGRT_STAMP_SUB 0  // diagnostic build: in-loop s_memtime stamps of the accelerator node step (load wait vs compute)
 #endif
@@ -435,8 +442,10 @@ __device__ __forceinline__ bool walk_begin(const SceneDev& S, Walk& W) {
     return true;
 }
 
+// Topology phase of a round: intersectNonLeaf steps until the lane stands on a leaf (returns false, W.cur = the leaf)
+// or has nothing left (returns true).
 template <bool COUNT>
-__device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t* __restrict__ stk, LaneCounters& cnt) {
+__device__ __forceinline__ bool walk_topology(const SceneDev& S, Walk& W, uint32_t* __restrict__ stk, LaneCounters& cnt) {
     const F3 o = W.o, d = W.d;
     uint32_t cur = W.cur;
     int sp = W.sp;
@@ -524,11 +533,19 @@ __device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t*
         sp += (second != REF_NONE) ? 2 : 0;
         cur = first;
     }
+    // the lane stands on a leaf
+    W.cur = cur;
+    W.sp = sp;
+    return false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t* __restrict__ stk, LaneCounters& cnt) {
+    if (walk_topology<COUNT>(S, W, stk, cnt)) return true;
     // ---- leaf phase ----
     if (COUNT) cnt.leaf++;
-    scan_leaf<COUNT>(S, S.leaves[cur & ~REF_LEAF], o, d, W.P, W.t, W.hit_rec, stk, sp, cnt);
+    scan_leaf<COUNT>(S, S.leaves[W.cur & ~REF_LEAF], W.o, W.d, W.P, W.t, W.hit_rec, stk, W.sp, cnt);
     W.cur = REF_NONE;
-    W.sp = sp;
     return false;
 }
 
@@ -545,6 +562,179 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F
     t = W.t;
     hit_rec = W.hit_rec;
 }
+
+#if CGRT_QUAD
+// ---------------------------------------------------------------------------------------------
+// Lane-cooperative leaf scan ("quad mode").  The frame ends when its hardest tiles do, and their waves spend most of
+// their life with a handful of live rays on an otherwise idle SIMD, paying ~170 dependent VALU per 4-wide node step.
+// When at most 16 lanes of a wave stand on an accelerated leaf, each such ray is spread over the 4 lanes of a quad for
+// the duration of that leaf scan: lane k of the quad tests child box k of a node (one slab test instead of four, no
+// sorting network: the children are ranked with three quad-local DPP compares) and triangle k of a run, and the quad
+// shares the owner lane's LDS stack slice.  The scan rule (LeafScan) is order-free, so the outcome is the one of the
+// scalar scan; the triangle arithmetic is the same test_record arithmetic, one triangle per lane.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(const uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(const float v) {
+    return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
+}
+#define CGRT_QP_XOR1 0xB1  // quad_perm [1,0,3,2]
+#define CGRT_QP_XOR2 0x4E  // quad_perm [2,3,0,1]
+#define CGRT_QP_XOR3 0x1B  // quad_perm [3,2,1,0]
+
+template <bool COUNT>
+__device__ __forceinline__ void scan_leaves_quad(const SceneDev& S, const unsigned long long owners, const bool owner, const LeafRec LR,
+                                                 Walk& W, uint32_t* __restrict__ s_stk_block, uint32_t* __restrict__ s_map,
+                                                 LaneCounters& cnt) {
+    const int lane = threadIdx.x & 63;
+    const int nown = __popcll(owners);
+    const int myrank = __popcll(owners & ((1ull << lane) - 1ull));
+    if (owner) s_map[myrank] = (uint32_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    const int Q = lane >> 2, k = lane & 3;
+    const bool valid = Q < nown;
+    const int src = valid ? (int)s_map[Q] : lane;
+    // the owner's per-ray constants, broadcast to its quad (all 64 lanes take part in the shuffles)
+    RayPre P;
+    P.inv = f3(__shfl(W.P.inv.x, src, 64), __shfl(W.P.inv.y, src, 64), __shfl(W.P.inv.z, src, 64));
+    P.oin = f3(__shfl(W.P.oin.x, src, 64), __shfl(W.P.oin.y, src, 64), __shfl(W.P.oin.z, src, 64));
+    P.oif = f3(__shfl(W.P.oif.x, src, 64), __shfl(W.P.oif.y, src, 64), __shfl(W.P.oif.z, src, 64));
+    const int sg = __shfl((int)((W.P.sx ? 1 : 0) | (W.P.sy ? 2 : 0) | (W.P.sz ? 4 : 0)), src, 64);
+    P.sx = (sg & 1) != 0;
+    P.sy = (sg & 2) != 0;
+    P.sz = (sg & 4) != 0;
+    P.regular = true;
+    const F3 o = f3(__shfl(W.o.x, src, 64), __shfl(W.o.y, src, 64), __shfl(W.o.z, src, 64));
+    const F3 d = f3(__shfl(W.d.x, src, 64), __shfl(W.d.y, src, 64), __shfl(W.d.z, src, 64));
+    const float t_in = __shfl(W.t, src, 64);
+    const uint32_t root = __shfl(LR.sub_root, src, 64);
+    const int sp0 = __shfl(W.sp, src, 64);
+    uint32_t* __restrict__ stk = s_stk_block + ((threadIdx.x & ~63u) + (uint32_t)src);  // the owner's LDS slice
+    LeafScan L;  // quad-uniform
+    L.best_t = t_in;
+    L.best_k = -1;
+    L.best_rec = REF_NONE;
+    L.onp_k = -1;
+    L.onp_rec = REF_NONE;
+    if (valid) {
+        const float inf = __builtin_inff();
+        uint32_t cur = root;
+        int sp = sp0;
+        for (;;) {
+            // ---- node phase: lane k tests child k of the 4-wide node ----
+            while (cur != REF_NONE && !(cur & REF_LEAF)) {
+                if (COUNT) {
+                    if (k == 0) cnt.sub++;
+                    if (first_active_lane()) cnt.w_sub++;
+                }
+                const char* rec = reinterpret_cast<const char*>(S.subnodes + cur + (uint32_t)(k >> 1));
+                const float2* bp = reinterpret_cast<const float2*>(rec + (k & 1) * 24);
+                const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+                const uint32_t ref = reinterpret_cast<const uint32_t*>(rec)[12 + (k & 1)];
+                float tn, tf;
+                slab_cons(P, f3(b0.x, b0.y, b1.x), f3(b1.y, b2.x, b2.y), tn, tf);
+                const float tc = fmaxf(L.best_t, 0.0f);  // see scan_leaf
+                const bool h = (tn <= tf) && (tf >= 0.0f) && (tn <= tc);
+                const float key = h ? tn : inf;
+                // rank of this child among the quad's four (ties by lane)
+                const float k1 = dpp_f32<CGRT_QP_XOR1>(key), k2 = dpp_f32<CGRT_QP_XOR2>(key), k3 = dpp_f32<CGRT_QP_XOR3>(key);
+                const int rank = ((k1 < key) || (k1 == key && (k ^ 1) < k) ? 1 : 0) + ((k2 < key) || (k2 == key && (k ^ 2) < k) ? 1 : 0) +
+                                 ((k3 < key) || (k3 == key && (k ^ 3) < k) ? 1 : 0);
+                const uint32_t hm = (uint32_t)((__ballot(h) >> (lane & ~3)) & 0xFull);
+                const int nhit = __popc(hm);
+                // the nearest hit child is next; the others are deferred far-to-near so that they pop near-to-far
+                if (h && rank >= 1) stk[(sp + nhit - 1 - rank) * CGRT_BLOCK] = ref;
+                sp += nhit > 0 ? nhit - 1 : 0;
+                uint32_t r0 = (h && rank == 0) ? ref : 0u;
+                r0 |= dpp_u32<CGRT_QP_XOR1>(r0);
+                r0 |= dpp_u32<CGRT_QP_XOR2>(r0);
+                cur = nhit > 0 ? r0 : REF_NONE;
+            }
+            // ---- triangle phase: lane k tests triangle k of the run ----
+            if (cur != REF_NONE) {
+                const uint32_t first = run_first(cur), n = run_count(cur);
+                for (uint32_t base = 0; base < n; base += 4) {
+                    bool has = false;
+                    float c_tt = inf;
+                    int c_k = 0x7fffffff, c_onk = -1;
+                    uint32_t c_rec = REF_NONE, c_onrec = REF_NONE;
+                    if (base + (uint32_t)k < n) {
+                        if (COUNT) cnt.tri++;
+                        const uint32_t r = first + base + (uint32_t)k;
+                        LeafScan T = L;  // evaluate this triangle against the quad-uniform state
+                        const float4* q = reinterpret_cast<const float4*>(S.tris + r);
+                        test_record(q[0], q[1], q[2], q[3], r, o, d, T);
+                        if (T.best_rec == r && (T.best_k != L.best_k || T.best_t != L.best_t || L.best_rec != r)) {
+                            has = true;
+                            c_tt = T.best_t;
+                            c_k = T.best_k;
+                            c_rec = r;
+                        }
+                        if (T.onp_k > L.onp_k) {
+                            c_onk = T.onp_k;
+                            c_onrec = r;
+                        }
+                    }
+                    if (COUNT && first_active_lane()) cnt.w_tri++;
+                    // quad reduction: lexicographic minimum of (t, scan position); last on-plane scan position
+#define CGRT_QRED(CTRL)                                                                          \
+    {                                                                                            \
+        const bool o_has = dpp_u32<CTRL>(has ? 1u : 0u) != 0u;                                   \
+        const float o_tt = dpp_f32<CTRL>(c_tt);                                                  \
+        const int o_k = (int)dpp_u32<CTRL>((uint32_t)c_k);                                       \
+        const uint32_t o_rec = dpp_u32<CTRL>(c_rec);                                             \
+        const bool take = o_has && (!has || o_tt < c_tt || (o_tt == c_tt && o_k < c_k));         \
+        has = has || o_has;                                                                      \
+        c_tt = take ? o_tt : c_tt;                                                               \
+        c_k = take ? o_k : c_k;                                                                  \
+        c_rec = take ? o_rec : c_rec;                                                            \
+        const int o_onk = (int)dpp_u32<CTRL>((uint32_t)c_onk);                                   \
+        const uint32_t o_onrec = dpp_u32<CTRL>(c_onrec);                                         \
+        const bool take2 = o_onk > c_onk;                                                        \
+        c_onk = take2 ? o_onk : c_onk;                                                           \
+        c_onrec = take2 ? o_onrec : c_onrec;                                                     \
+    }
+                    CGRT_QRED(CGRT_QP_XOR1)
+                    CGRT_QRED(CGRT_QP_XOR2)
+#undef CGRT_QRED
+                    if (has) {
+                        L.best_t = c_tt;
+                        L.best_k = c_k;
+                        L.best_rec = c_rec;
+                    }
+                    if (c_onk > L.onp_k) {
+                        L.onp_k = c_onk;
+                        L.onp_rec = c_onrec;
+                    }
+                }
+            }
+            // ---- pop (all four lanes read the same slot) ----
+            if (sp <= sp0) break;
+            sp -= 1;
+            cur = stk[sp * CGRT_BLOCK];
+        }
+    }
+    // results back to the owner lanes (quad lane 0 of quad `myrank`)
+    const int ql = 4 * myrank;
+    const float r_t = __shfl(L.best_t, ql, 64);
+    const int r_k = __shfl(L.best_k, ql, 64);
+    const uint32_t r_rec = __shfl(L.best_rec, ql, 64);
+    const int r_onk = __shfl(L.onp_k, ql, 64);
+    const uint32_t r_onrec = __shfl(L.onp_rec, ql, 64);
+    if (owner) {
+        if (r_onk >= 0) {
+            W.t = 0.0f;
+            W.hit_rec = r_onrec;
+        } else if (r_k >= 0) {
+            W.t = r_t;
+            W.hit_rec = r_rec;
+        }
+    }
+}
+
+#endif  // CGRT_QUAD
 
 // Spheres (bvh.cpp:878-879), result assembly and the accepted hit's interpolated normal
 // (ray_tracing.cpp:94-107), which depends only on the final (triangle, t).
@@ -650,6 +840,51 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
     LaneCounters cnt;
+#if CGRT_QUAD
+    {
+        __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];
+        uint32_t* map = s_map + (threadIdx.x >> 6) * 16;
+        uint32_t* stk = s_stk + threadIdx.x;
+        const size_t pix = (size_t)y * F.W + x;
+        Walk W;
+        W.t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
+        bool alive = false;
+        if (active) {
+            primary_ray(C, F.W, F.H, x, y, W.o, W.d);
+            alive = walk_begin(S, W);
+            if (!alive) finish_ray(S, W.o, W.d, W.t, W.hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
+        }
+        // wave-uniform round loop: every lane of the wave reaches the leaf phase together, so that idle lanes can be
+        // lent to the rays that are still alive (scan_leaves_quad)
+        while (__any(alive)) {
+            bool at_leaf = false;
+            if (alive) {
+                if (walk_topology<COUNT || STAMP>(S, W, stk, cnt)) {
+                    finish_ray(S, W.o, W.d, W.t, W.hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
+                    alive = false;
+                } else {
+                    at_leaf = true;
+                }
+            }
+            LeafRec LR;
+            LR.first = 0;
+            LR.count = 0;
+            LR.sub_root = REF_NONE;
+            LR.pad = 0;
+            if (at_leaf) {
+                LR = S.leaves[W.cur & ~REF_LEAF];
+                if (COUNT || STAMP) cnt.leaf++;
+            }
+            const bool qok = at_leaf && (LR.sub_root != REF_NONE) && W.P.regular && (SUB_WIDTH == 4);
+            const unsigned long long qm = __ballot(qok);
+            const int nq = __popcll(qm);
+            const bool quad = nq > 0 && nq <= CGRT_QUAD_MAX_RAYS;
+            if (quad) scan_leaves_quad<COUNT || STAMP>(S, qm, qok, LR, W, s_stk, map, cnt);
+            if (at_leaf && !(quad && qok)) scan_leaf<COUNT || STAMP>(S, LR, W.o, W.d, W.P, W.t, W.hit_rec, stk, W.sp, cnt);
+            if (at_leaf) W.cur = REF_NONE;
+        }
+    }
+#else
     if (active) {
         F3 o, d;
         primary_ray(C, F.W, F.H, x, y, o, d);
@@ -659,6 +894,7 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
         const size_t pix = (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
+#endif
     if (STAMP) {
         const unsigned long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long nactive = __popcll(__ballot(active));
