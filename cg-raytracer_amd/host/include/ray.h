@@ -1,12 +1,3 @@
-// Mirror of framework/include/ray.h:9-13.
+// Forwarder: the types of the reference header of this name live in cgrt_host_types.h.
 #pragma once
-#include <limits>
-
-#include "cgrt_vec.h"
-
-struct Ray {
-    cgrt::vec3 origin{0.0f};
-    cgrt::vec3 direction{0.0f, 0.0f, -1.0f};
-    float t{std::numeric_limits<float>::max()};
-};
-static_assert(sizeof(Ray) == 28, "Ray layout (ray.h:9-13)");
+#include "cgrt_host_types.h"
