@@ -52,7 +52,12 @@ class Counters(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("reflection_rays", C.c_uint64), ("levels", C.c_int32),
-                ("device_ms", C.c_float)]
+                ("device_ms", C.c_float), ("soft_shadow_rays", C.c_uint64)]
+
+
+class SoftShadows(C.Structure):
+    _fields_ = [("spherical", C.c_void_p), ("unit_vectors", C.c_void_p), ("nspherical", C.c_uint32), ("samples", C.c_uint32),
+                ("nunits", C.c_uint32), ("seed", C.c_uint32), ("closest_hit", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -95,7 +100,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_record_sizes",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
 ]  # fmt: skip
@@ -136,6 +141,7 @@ def lib() -> C.CDLL:
     L.cgrt_trace_primary_device.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp, vp]
     L.cgrt_generate_rays.argtypes = [vp, C.POINTER(Camera)] + [i32] * 6 + [vp]
     L.cgrt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats)]
+    L.cgrt_render_soft.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, vp, C.POINTER(RenderStats)]
     L.cgrt_count_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [C.POINTER(Counters)]
     L.cgrt_count_batch.argtypes = [vp, vp, u64, C.POINTER(Counters)]
     L.cgrt_debug_gather_calibration.argtypes = [i32, u64, i32]
@@ -193,6 +199,15 @@ def set_primary_mode(mode: int) -> None:
 
 def device_count() -> int:
     return int(lib().cgrt_device_count())
+
+
+def unit_vector_table(n: int = 1 << 16, seed: int = 0) -> np.ndarray:
+    """n draws of the reference's randomUnitVector() (main.cpp:46-59: three N(0,1) floats, glm::normalize) as input data
+    for render_soft.  Any generator will do -- the table is data, not part of the parity contract."""
+    g = np.random.default_rng(seed).standard_normal((n, 3)).astype(np.float32)
+    d = (g[:, 0] * g[:, 0] + g[:, 1] * g[:, 1]) + g[:, 2] * g[:, 2]
+    inv = np.float32(1.0) / np.sqrt(d, dtype=np.float32)
+    return np.ascontiguousarray(g * inv[:, None], dtype=np.float32)
 
 
 class Scene:
@@ -294,6 +309,20 @@ class Scene:
         st = RenderStats()
         c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
         _check(lib().cgrt_render(self._h, C.byref(c), W, H, _ptr(lights), len(lights), max_level, _ptr(rgb), C.byref(st)))
+        return rgb, {k: getattr(st, k) for k, _ in st._fields_}
+
+    def render_soft(self, cam, W: int, H: int, spherical, units, samples: int = 200, seed: int = 0, lights=None, max_level: int = 2,
+                    closest_hit: bool = False):
+        """cgrt_render_soft: + spherical lights (n x 7 {position, radius, color}) sampled with `samples` shadow rays per hit
+        (main.cpp:168-218); `units` (n x 3) are the randomUnitVector() draws, see unit_vector_table()."""
+        lights = _f32(self.sd.point_lights if lights is None else lights, (-1, 6))
+        spherical = _f32(spherical, (-1, 7))
+        units = _f32(units, (-1, 3))
+        rgb = np.zeros((W * H, 3), np.float32)
+        st = RenderStats()
+        q = SoftShadows(spherical.ctypes.data, units.ctypes.data, len(spherical), samples, len(units), seed, int(closest_hit))
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_render_soft(self._h, C.byref(c), W, H, _ptr(lights), len(lights), C.byref(q), max_level, _ptr(rgb), C.byref(st)))
         return rgb, {k: getattr(st, k) for k, _ in st._fields_}
 
     def generate_rays(self, cam, W: int, H: int, rect=None) -> np.ndarray:
@@ -401,6 +430,7 @@ def host_lib() -> C.CDLL:
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
         H.cgrt_host_last_error.restype = C.c_char_p
         H.cgrt_host_render.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, vp, vp]
+        H.cgrt_host_render_soft.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32, u32, vp, i32, i32, i32, vp, vp]
         H.cgrt_host_load_obj.argtypes = [C.c_char_p, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp]
         H.cgrt_host_write_bmp.argtypes = [C.c_char_p, vp, i32, i32]
         H.cgrt_host_selftest.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, C.POINTER(i32)]
@@ -421,6 +451,27 @@ def host_render(sd: SceneData, cam, W: int, H: int, max_level: int = 2):
     if rc:
         raise RuntimeError("cgrt_host_render: " + Hl.cgrt_host_last_error().decode())
     return rgb, dict(primary=int(st[0]), shadow=int(st[1]), reflection=int(st[2]), seconds_device=float(st[3]), seconds_total=float(st[4]))
+
+
+def host_render_soft(sd: SceneData, cam, W: int, H: int, spherical, units=None, samples: int = 200, seed: int = 0, lights=None,
+                     max_level: int = 2):
+    """renderRayTracing of the C++ host mirror for a scene with spherical lights (soft shadows, main.cpp:168-218).
+    units=None uses the mirror's own gaussian table (SoftShadowSampler::gaussian)."""
+    Hl = host_lib()
+    pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+    tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
+    lights, camv = _f32(sd.point_lights if lights is None else lights, (-1, 6)), _f32(cam, (9,))
+    spherical = _f32(spherical, (-1, 7))
+    units = np.zeros((0, 3), np.float32) if units is None else _f32(units, (-1, 3))
+    rgb = np.zeros((W * H, 3), np.float32)
+    st = np.zeros(6, np.float64)
+    rc = Hl.cgrt_host_render_soft(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(lights), len(lights),
+                                  _ptr(spherical), len(spherical), _ptr(units), len(units), samples, seed, _ptr(camv), W, H, max_level,
+                                  _ptr(rgb), _ptr(st))
+    if rc:
+        raise RuntimeError("cgrt_host_render_soft: " + Hl.cgrt_host_last_error().decode())
+    return rgb, dict(primary=int(st[0]), shadow=int(st[1]), reflection=int(st[2]), soft_shadow=int(st[3]), seconds_device=float(st[4]),
+                     seconds_total=float(st[5]))
 
 
 def host_load_obj(path: str, normalize: bool = False) -> SceneData:

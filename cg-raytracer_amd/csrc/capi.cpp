@@ -472,11 +472,17 @@ int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters
 
 // ------------------------------------------------------------------------------------------------
 // renderRayTracing / getFinalColor (src/main.cpp:298-310, :648-720) as a device wavefront
-int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level, float* rgb,
-                CgrtRenderStats* stats) {
+static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
+                       int max_level, float* rgb, CgrtRenderStats* stats) {
     if (!s || !cam || !rgb || (nlights && !lights)) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     if (W <= 0 || H <= 0 || max_level < 0 || max_level > 16) return fail(CGRT_E_ARG, "bad frame size or recursion depth");
+    const unsigned SL = soft ? soft->nspherical : 0;
+    if (SL) {
+        if (!soft->spherical || !soft->unit_vectors || soft->nunits == 0 || soft->samples == 0 || soft->samples > (1u << 24))
+            return fail(CGRT_E_ARG, "soft shadows need lights, a unit-vector table and 1..2^24 samples");
+        if ((unsigned long long)W * H > 0x7fffffffull) return fail(CGRT_E_ARG, "frame too large");
+    }
     HIP_TRY(hipSetDevice(s->device));
     const unsigned long long npix = (unsigned long long)W * H;
     const unsigned L = nlights;
@@ -484,7 +490,7 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
     FrameDev F;
     if (!make_frame(W, H, 0, 0, W, H, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame");
     const unsigned long long n = (unsigned long long)F.nblocks * 256ull;  // items: the frame in the primary kernel's order
-    DevBuf rays, nrays, hits, normals, srays, shits, sdist, dlights, levels, drgb, dstats, ipix;
+    DevBuf rays, nrays, hits, normals, srays, shits, sdist, dlights, levels, drgb, dstats, ipix, dslights, dunits, dlit;
     HIP_TRY(ipix.alloc(n * 4));
     HIP_TRY(rays.alloc(n * 28));
     HIP_TRY(nrays.alloc(n * 28));
@@ -496,9 +502,23 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
     HIP_TRY(dlights.alloc((size_t)L * 24));
     HIP_TRY(levels.alloc((size_t)(max_level > 0 ? max_level : 1) * n * 32));
     HIP_TRY(drgb.alloc(npix * 12));
-    HIP_TRY(dstats.alloc(3 * sizeof(unsigned long long)));
+    HIP_TRY(dstats.alloc(4 * sizeof(unsigned long long)));
     if (L) HIP_TRY(hipMemcpy(dlights.p, lights, (size_t)L * 24, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dstats.p, 0, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(dstats.p, 0, 4 * sizeof(unsigned long long)));
+    SoftDev Q{};
+    if (SL) {
+        HIP_TRY(dslights.alloc((size_t)SL * 28));
+        HIP_TRY(dunits.alloc((size_t)soft->nunits * 12));
+        HIP_TRY(dlit.alloc(n * SL * 4));
+        HIP_TRY(hipMemcpy(dslights.p, soft->spherical, (size_t)SL * 28, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dunits.p, soft->unit_vectors, (size_t)soft->nunits * 12, hipMemcpyHostToDevice));
+        Q.lights = dslights.as<float>();
+        Q.units = dunits.as<float>();
+        Q.nlights = SL;
+        Q.samples = soft->samples;
+        Q.nunits = soft->nunits;
+        Q.seed = soft->seed;
+    }
     const CameraDev C = make_camera(*cam);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -515,15 +535,23 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
             const int spawn = level + 1 < max_level;
             HIP_TRY(launch_spawn_shadow(cur, hits.as<CgrtHitDev>(), n, dlights.as<float>(), L, srays.as<float>(), sdist.as<float>(), nullptr));
             HIP_TRY(launch_trace_batch(s->dev, srays.as<float>(), n * L, shits.as<CgrtHitDev>(), nullptr, nullptr, nullptr));
+            if (SL) {
+                Q.level = (uint32_t)level;
+                HIP_TRY(hipMemsetAsync(dlit.p, 0, n * SL * 4, nullptr));
+                HIP_TRY(launch_soft_shadow(s->dev, Q, cur, hits.as<CgrtHitDev>(), ipix.as<int>(), n, dlit.as<uint32_t>(), soft->closest_hit == 0,
+                                           nullptr));
+            }
             HIP_TRY(launch_shade(cur, hits.as<CgrtHitDev>(), normals.as<float>(), shits.as<CgrtHitDev>(), sdist.as<float>(), n,
-                                 static_cast<const float*>(s->d_materials), dlights.as<float>(), L, spawn,
-                                 levels.as<float>() + (size_t)level * n * 8, nxt, dstats.as<unsigned long long>(), nullptr));
+                                 static_cast<const float*>(s->d_materials), dlights.as<float>(), L, dslights.as<float>(), SL,
+                                 dlit.as<uint32_t>(), Q.samples, spawn, levels.as<float>() + (size_t)level * n * 8, nxt,
+                                 dstats.as<unsigned long long>(), nullptr));
             nlev = level + 1;
-            unsigned long long h[3];
+            unsigned long long h[4];
             HIP_TRY(hipMemcpy(h, dstats.p, sizeof(h), hipMemcpyDeviceToHost));  // also the level's sync point
             const unsigned long long spawned = h[2] - st.reflection_rays;
             st.shadow_rays = h[1];
             st.reflection_rays = h[2];
+            st.soft_shadow_rays = h[3];
             if (!spawn || spawned == 0) break;
             HIP_TRY(launch_trace_batch(s->dev, nxt, n, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
             std::swap(cur, nxt);
@@ -545,6 +573,15 @@ int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* 
     HIP_TRY(hipMemcpy(rgb, drgb.p, npix * 12, hipMemcpyDeviceToHost));
     if (stats) *stats = st;
     return CGRT_OK;
+}
+
+int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level, float* rgb,
+                CgrtRenderStats* stats) {
+    return render_impl(s, cam, W, H, lights, nlights, nullptr, max_level, rgb, stats);
+}
+int cgrt_render_soft(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
+                     int max_level, float* rgb, CgrtRenderStats* stats) {
+    return render_impl(s, cam, W, H, lights, nlights, soft, max_level, rgb, stats);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -170,6 +170,34 @@ CGRT_HD bool ray_sphere(F3 c, float radius, F3 o, F3 d, float& t, F3& nrm) {
     return true;
 }
 
+// ---- soft shadows (main.cpp:168-218): which caller-supplied randomUnitVector() draw sample `smp` of (pixel, recursion
+//      level, spherical light) uses.  Upstream draws from std::random_device (:46-59), which nothing can reproduce; the
+//      draws are a table here and this integer hash (murmur3's 32-bit finaliser, chained) picks from it -- include/cgrt.h.
+CGRT_HD uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+CGRT_HD uint32_t soft_sample_index(uint32_t seed, uint32_t pixel, uint32_t level, uint32_t light, uint32_t smp, uint32_t nunits) {
+    uint32_t h = mix32(seed ^ 0x9e3779b9u);
+    h = mix32(h ^ pixel);
+    h = mix32(h ^ (level * 0x01000193u + light));
+    h = mix32(h ^ smp);
+    return h % nunits;
+}
+// One soft-shadow sample ray (main.cpp:177-181): towards position + radius * u, started 0.001 along; t = distance from the
+// shifted origin to the sample point (`lightT`, :180).
+CGRT_HD void soft_shadow_ray(F3 pointOn, F3 lpos, float radius, F3 u, F3& o, F3& d, float& t) {
+    const F3 rp = add(lpos, f3(radius * u.x, radius * u.y, radius * u.z));
+    d = normalize(sub(rp, pointOn));
+    const float eps = (float)(0.001);
+    o = add(pointOn, f3(eps * d.x, eps * d.y, eps * d.z));
+    t = length(sub(o, rp));
+}
+
 // ---- camera: glm::qua(euler), qua * vec3 (glm 0.9.9.8), Trackball::generateRay ----
 struct Q4 {
     float w, x, y, z;

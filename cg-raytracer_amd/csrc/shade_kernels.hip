@@ -4,7 +4,8 @@
 // :241-264), and after the last level one kernel folds the levels back (color = direct + reflected * ks, :262).
 // Paths are never compacted: item i of every level belongs to the same pixel (items are in the primary kernel's
 // frame order -- tiles, super-tiles -- so every batch stays tile-coherent); dead paths carry a "null ray" that fails the
-// root gate of the traversal at once.  Point lights only (spherical lights draw from std::random_device upstream).
+// root gate of the traversal at once.  Spherical lights (:168-218) are sampled by k_soft_shadow (trace_kernels.hip), which
+// leaves the number of unoccluded samples per (item, light); the draws of randomUnitVector() are a caller-supplied table.
 // Arithmetic follows the reference's expression order (cgrt_math.h); pow(float, float) is powf (device libm: the last
 // ulp may differ from glibc's -- the RGB parity bar is 1e-5 absolute).
 #include <hip/hip_runtime.h>
@@ -54,10 +55,11 @@ __global__ void k_spawn_shadow(const float* __restrict__ rays, const CgrtHitDev*
 }
 
 // shading (main.cpp:219-232) + shade (:241-264) for one level.  lvl: per item {direct.xyz, flags} {ks.xyz, 0};
-// flags bit0 = hit, bit1 = a mirror ray was spawned into next_rays[i].  stats[0..2] += hits, real shadow rays, mirror rays.
+// flags bit0 = hit, bit1 = a mirror ray was spawned into next_rays[i].  stats[0..3] += hits, real shadow rays, mirror rays, soft-shadow samples.
 __global__ void k_shade(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits, const float* __restrict__ normals,
                         const CgrtHitDev* __restrict__ shits, const float* __restrict__ sdist, unsigned long long n,
-                        const float* __restrict__ materials, const float* __restrict__ lights, unsigned nlights, int spawn,
+                        const float* __restrict__ materials, const float* __restrict__ lights, unsigned nlights,
+                        const float* __restrict__ slights, unsigned nslights, const uint32_t* __restrict__ lit, unsigned samples, int spawn,
                         float4* __restrict__ lvl, float* __restrict__ next_rays, unsigned long long* __restrict__ stats) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -75,6 +77,24 @@ __global__ void k_shade(const float* __restrict__ rays, const CgrtHitDev* __rest
         const float shininess = mid >= 0 ? materials[8 * mid + 6] : 1.0f;
         const float eps = 0.001f;
         F3 result = f3(0.f, 0.f, 0.f);
+        const float dn0 = dot(nrm, d);  // glm::reflect(I, N) = I - N * dot(N, I) * 2
+        const F3 refl0 = normalize(sub(d, scale(scale(nrm, dn0), 2.0f)));
+        for (unsigned l = 0; l < nslights; l++) {  // spherical lights first (main.cpp:168-218)
+            const F3 lpos = ldv(slights + 7 * l), lcol = ldv(slights + 7 * l + 4);
+            const F3 toLight = normalize(sub(lpos, pointOn));
+            const float dc = dot(toLight, nrm);
+            const F3 dif = dc <= 0 ? f3(0.f, 0.f, 0.f) : f3(lcol.x * kd.x * dc, lcol.y * kd.y * dc, lcol.z * kd.z * dc);
+            const float sc = dot(refl0, toLight);
+            F3 spec = f3(0.f, 0.f, 0.f);
+            if (!(sc <= 0)) {
+                const float p = __builtin_powf(sc, shininess);
+                spec = f3(lcol.x * ks.x * p, lcol.y * ks.y * p, lcol.z * ks.z * p);
+            }
+            // softShadowCounter: `samples` additions of 1.0f (exact), then / 200.0f (:200)
+            const float counter = (float)lit[i * nslights + l] / (float)samples;
+            result = add(result, scale(dif, counter));
+            result = add(result, scale(spec, counter));
+        }
         for (unsigned l = 0; l < nlights; l++) {
             const F3 lpos = ldv(lights + 6 * l), lcol = ldv(lights + 6 * l + 3);
             const F3 toLight = normalize(sub(lpos, pointOn));
@@ -121,6 +141,7 @@ __global__ void k_shade(const float* __restrict__ rays, const CgrtHitDev* __rest
         if (h) {
             atomicAdd(stats + 0, h);
             atomicAdd(stats + 1, h * nlights);
+            if (nslights) atomicAdd(stats + 3, h * nslights * samples);
         }
         if (s) atomicAdd(stats + 2, s);
     }
@@ -160,11 +181,12 @@ hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsign
     return hipGetLastError();
 }
 hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
-                        unsigned long long n, const float* materials, const float* lights, unsigned nlights, int spawn, float* lvl,
-                        float* next_rays, unsigned long long* stats, hipStream_t s) {
+                        unsigned long long n, const float* materials, const float* lights, unsigned nlights, const float* slights,
+                        unsigned nslights, const uint32_t* lit, unsigned samples, int spawn, float* lvl, float* next_rays,
+                        unsigned long long* stats, hipStream_t s) {
     if (n)
         hipLaunchKernelGGL(k_shade, dim3(grid_for(n, 256)), dim3(256), 0, s, rays, hits, normals, shits, sdist, n, materials, lights, nlights,
-                           spawn, reinterpret_cast<float4*>(lvl), next_rays, stats);
+                           slights, nslights, lit, samples, spawn, reinterpret_cast<float4*>(lvl), next_rays, stats);
     return hipGetLastError();
 }
 hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s) {

@@ -17,6 +17,13 @@ struct CgrtHitDev {
     uint32_t hit;
 };
 
+// Soft-shadow sampling of spherical lights (main.cpp:168-218) for one recursion level.
+struct SoftDev {
+    const float* lights;  // nlights x 7 {position, radius, color} (SphericalLight, scene.h:47-51)
+    const float* units;   // nunits x 3 unit vectors: the randomUnitVector() draws (main.cpp:46-59)
+    uint32_t nlights, samples, nunits, seed, level;
+};
+
 // counters (optional): 5 x u64 device words {rays, inner_visits, leaf_visits, tri_tests, sub_visits}, accumulated.
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
                                 unsigned long long* counters, hipStream_t stream);
@@ -29,6 +36,9 @@ hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, c
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
                               unsigned long long* counters, hipStream_t stream);
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);
+// lit[item * nlights + l] += samples of spherical light l that reach it from item's hit point (zeroed by the caller)
+hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
+                              unsigned long long nitems, uint32_t* lit, int anyhit, hipStream_t stream);
 
 // frame-ordered primary rays for the shading wavefront: n items = F.nblocks * 256; item_pixels[i] = y*W+x or -1
 hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, float* rays, int* item_pixels, hipStream_t stream);
@@ -36,8 +46,9 @@ hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, flo
 hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsigned long long n, const float* lights, unsigned nlights,
                                float* srays, float* sdist, hipStream_t s);
 hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
-                        unsigned long long n, const float* materials, const float* lights, unsigned nlights, int spawn, float* lvl,
-                        float* next_rays, unsigned long long* stats, hipStream_t s);
+                        unsigned long long n, const float* materials, const float* lights, unsigned nlights, const float* slights,
+                        unsigned nslights, const uint32_t* lit, unsigned samples, int spawn, float* lvl, float* next_rays,
+                        unsigned long long* stats, hipStream_t s);
 hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
 hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
                                hipStream_t s);

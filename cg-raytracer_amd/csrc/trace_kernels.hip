@@ -549,7 +549,10 @@ __device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t*
     return false;
 }
 
-template <bool COUNT>
+// ANYHIT: stop after the first leaf that accepted a triangle.  The walk up to there is the reference's, so the hit FLAG
+// is the reference's (some acceptance happens upstream iff one happens in the first leaf that has one); t and the
+// record are those of that leaf, not the final ones.
+template <bool COUNT, bool ANYHIT = false>
 __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
                                           uint32_t* __restrict__ stk, LaneCounters& cnt) {
     Walk W;
@@ -558,6 +561,7 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F
     W.t = t;
     if (walk_begin(S, W))
         while (!walk_round<COUNT>(S, W, stk, cnt)) {
+            if (ANYHIT && W.hit_rec != REF_NONE) break;
         }
     t = W.t;
     hit_rec = W.hit_rec;
@@ -1078,6 +1082,57 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
     if (COUNT) flush_counters(cnt, active, counters);
 }
 
+// Soft shadows of spherical lights (main.cpp:168-218): `samples` shadow rays per (hit item, light), generated in
+// registers from the item's ray + hit and the unit-vector table (no ray buffer: 200 samples x 2 M hits would be 12 GB),
+// traversed, and counted: lit[item * nlights + l] = number of samples with !intersect || ray.t > lightT (:183-199).
+// Thread g = (item * nlights + l) * samples + smp: a wave's rays leave one or two surface points towards one small
+// sphere, the most coherent batch this library sees.  ANYHIT stops a ray at its first accepting leaf: the count needs
+// the hit flag only (an accepted t is below lightT by construction, or 0 from the on-plane rule, never above).
+template <bool ANYHIT>
+__global__ CGRT_LB void k_soft_shadow(SceneDev S, SoftDev Q, const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits,
+                                      const int* __restrict__ item_pixels, unsigned long long nthreads, uint32_t* __restrict__ lit) {
+    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    const unsigned long long g = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
+    const bool in = g < nthreads;
+    const unsigned long long key = in ? g / Q.samples : 0ull;  // item * nlights + l
+    const uint32_t smp = in ? (uint32_t)(g - key * Q.samples) : 0u;
+    const unsigned long long item = key / Q.nlights;
+    const uint32_t l = (uint32_t)(key - item * Q.nlights);
+    bool is_lit = false;
+    const bool live = in && hits[item].hit != 0;
+    if (live) {
+        const float* r = rays + 7 * item;
+        const F3 pointOn = add(f3(r[0], r[1], r[2]), scale(f3(r[3], r[4], r[5]), hits[item].t));
+        const float* L = Q.lights + 7 * l;
+        const float* u = Q.units + 3ull * soft_sample_index(Q.seed, (uint32_t)item_pixels[item], Q.level, l, smp, Q.nunits);
+        F3 o, d;
+        float t;
+        soft_shadow_ray(pointOn, f3(L[0], L[1], L[2]), L[3], f3(u[0], u[1], u[2]), o, d, t);
+        const float lightT = t;
+        uint32_t hit_rec = REF_NONE;
+        LaneCounters cnt;
+        walk_tree<false, ANYHIT>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
+        bool hit = hit_rec != REF_NONE;
+        if (!ANYHIT || !hit) {  // spheres come after the meshes in BoundingVolumeHierarchy::intersect (bvh.cpp:875-880)
+            for (uint32_t k = 0; k < S.nspheres; k++) {
+                F3 nrm;
+                hit |= ray_sphere(f3(S.spheres[k].c[0], S.spheres[k].c[1], S.spheres[k].c[2]), S.spheres[k].radius, o, d, t, nrm);
+            }
+        }
+        is_lit = !hit || t > lightT;
+    }
+    // one atomic per (wave, key): a wave's keys are consecutive
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const unsigned long long k0 = __shfl(key, first);
+        const unsigned long long same = __ballot(live && key == k0);
+        const uint32_t c = (uint32_t)__popcll(__ballot(live && key == k0 && is_lit));
+        if ((int)(threadIdx.x & 63) == first && c) atomicAdd(lit + k0, c);
+        todo &= ~same;
+    }
+}
+
 __global__ __launch_bounds__(CGRT_BLOCK) void k_generate_rays(CameraDev C, int W, int H, int x0, int y0, int x1, int y1,
                                                               float* __restrict__ rays) {
     const unsigned long long i = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
@@ -1286,6 +1341,18 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
         hipLaunchKernelGGL(k_trace_batch<true>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, rays, n, hits, normals, counters);
     else
         hipLaunchKernelGGL(k_trace_batch<false>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, rays, n, hits, normals, counters);
+    return hipGetLastError();
+}
+hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
+                              unsigned long long nitems, uint32_t* lit, int anyhit, hipStream_t stream) {
+    const unsigned long long nthreads = nitems * Q.nlights * Q.samples;
+    if (nthreads == 0) return hipSuccess;
+    const unsigned long long blocks = (nthreads + CGRT_BLOCK - 1) / CGRT_BLOCK;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (anyhit)
+        hipLaunchKernelGGL(k_soft_shadow<true>, dim3((unsigned)blocks), dim3(CGRT_BLOCK), 0, stream, S, Q, rays, hits, item_pixels, nthreads, lit);
+    else
+        hipLaunchKernelGGL(k_soft_shadow<false>, dim3((unsigned)blocks), dim3(CGRT_BLOCK), 0, stream, S, Q, rays, hits, item_pixels, nthreads, lit);
     return hipGetLastError();
 }
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream) {

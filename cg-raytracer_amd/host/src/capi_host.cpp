@@ -71,6 +71,45 @@ int cgrt_host_render(const float* pos_nrm, uint32_t nverts, const uint32_t* tri,
     }
 }
 
+// + spherical lights (S x 7: position, radius, color) sampled from `units` (nunits x 3, 0 -> SoftShadowSampler::gaussian()).
+// stats: primary, shadow, reflection, soft-shadow ray counts, device seconds, total seconds.
+int cgrt_host_render_soft(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
+                          const float* materials, uint32_t nmesh, const float* lights, uint32_t nlights, const float* spherical,
+                          uint32_t nspherical, const float* units, uint32_t nunits, uint32_t samples, uint32_t seed, const float* cam, int W,
+                          int H, int maxLevel, float* rgb, double* stats) {
+    try {
+        Scene sc = scene_from_arrays(pos_nrm, nverts, tri, tri_mesh, ntris, materials, nmesh, lights, nlights);
+        for (uint32_t i = 0; i < nspherical; i++) {
+            const float* q = spherical + 7 * i;
+            sc.sphericalLight.push_back(SphericalLight{cgrt::vec3(q[0], q[1], q[2]), q[3], cgrt::vec3(q[4], q[5], q[6])});
+        }
+        SoftShadowSampler sampler;
+        if (nunits) {
+            for (uint32_t i = 0; i < nunits; i++) sampler.units.push_back(cgrt::vec3(units[3 * i], units[3 * i + 1], units[3 * i + 2]));
+        } else {
+            sampler = SoftShadowSampler::gaussian();
+        }
+        sampler.samples = samples;
+        sampler.seed = seed;
+        BoundingVolumeHierarchy bvh(&sc);
+        Trackball camera(cam[7], cam[8], cam[6]);
+        camera.setCamera(cgrt::vec3(cam[0], cam[1], cam[2]), cgrt::vec3(cam[3], cam[4], cam[5]), cam[6]);
+        RenderStats st = renderToBuffer(sc, camera, bvh, W, H, rgb, maxLevel, &sampler);
+        if (stats) {
+            stats[0] = (double)st.primary;
+            stats[1] = (double)st.shadow;
+            stats[2] = (double)st.reflection;
+            stats[3] = (double)st.softShadow;
+            stats[4] = st.seconds_device;
+            stats[5] = st.seconds_total;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // Loads an OBJ with the host loader and reports sizes; a second call with buffers copies the flat arrays out.
 int cgrt_host_load_obj(const char* path, int normalize, uint32_t* nverts, uint32_t* ntris, uint32_t* nmesh, float* pos_nrm, uint32_t* tri,
                        uint32_t* tri_mesh, float* materials) {

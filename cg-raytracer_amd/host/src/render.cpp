@@ -1,9 +1,11 @@
 // Wavefront restatement of the reference's render driver (src/main.cpp:61-310, :648-720).  See render.h.
 #include "render.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <random>
 
 namespace {
 using cgrt::vec3;
@@ -34,19 +36,55 @@ struct LevelItem {  // what the backward pass needs: color = direct + reflectedC
     int child;  // item of the next level, -1 if none
     uint32_t parent;
 };
+uint32_t mix32(uint32_t h) {  // murmur3's 32-bit finaliser
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
 }  // namespace
 
+SoftShadowSampler SoftShadowSampler::gaussian(uint32_t n, uint32_t engineSeed, uint32_t samples, uint32_t seed) {
+    SoftShadowSampler s;
+    s.samples = samples;
+    s.seed = seed;
+    s.units.reserve(n);
+    std::default_random_engine generator(engineSeed);
+    std::normal_distribution<float> distribution(0.0f, 1.0f);
+    for (uint32_t i = 0; i < n; i++) {
+        const float y = distribution(generator);
+        const float x = distribution(generator);
+        const float z = distribution(generator);
+        s.units.push_back(cgrt::normalize(vec3(y, x, z)));
+    }
+    return s;
+}
+const cgrt::vec3& SoftShadowSampler::draw(uint32_t pixel, uint32_t level, uint32_t light, uint32_t smp) const {
+    uint32_t h = mix32(seed ^ 0x9e3779b9u);
+    h = mix32(h ^ pixel);
+    h = mix32(h ^ (level * 0x01000193u + light));
+    h = mix32(h ^ smp);
+    return units[h % (uint32_t)units.size()];
+}
+
 RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
-                           int maxLevel) {
+                           int maxLevel, const SoftShadowSampler* sampler) {
     RenderStats st;
+    SoftShadowSampler fallback;
+    if (!scene.sphericalLight.empty() && (!sampler || sampler->units.empty() || sampler->samples == 0)) {
+        fallback = SoftShadowSampler::gaussian();
+        sampler = &fallback;
+    }
     const auto t_begin = Clock::now();
     const size_t npix = (size_t)W * H;
     const float eps = 0.001;  // main.cpp:110, :255
     std::vector<Ray> rays(npix);
     std::vector<HitInfo> his(npix);
     std::vector<uint8_t> hit(npix, 0);
-    std::vector<uint32_t> parent(npix);
-    for (size_t i = 0; i < npix; i++) parent[i] = (uint32_t)i;
+    std::vector<uint32_t> parent(npix), pixel(npix);
+    for (size_t i = 0; i < npix; i++) parent[i] = pixel[i] = (uint32_t)i;
     std::vector<std::vector<LevelItem>> levels;
     if (maxLevel >= 1) {  // trace(0): `level >= maxLevel` -> black without tracing (main.cpp:267)
         auto t0 = Clock::now();
@@ -83,9 +121,52 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
             st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
             st.shadow += srays.size();
         }
+        // ---- soft shadows: `samples` rays per hit x spherical light (main.cpp:168-200), in bounded batches ----
+        const size_t SL = scene.sphericalLight.size();
+        std::vector<uint32_t> litCount(SL ? n * SL : 0, 0);
+        if (SL) {
+            const uint32_t S = sampler->samples;
+            const size_t chunkItems = std::max<size_t>(1, (size_t(1) << 22) / (SL * S));  // ~4 M rays per batch
+            std::vector<Ray> qr;
+            std::vector<float> lightT;
+            std::vector<uint32_t> slot;
+            std::vector<HitInfo> qh;
+            std::vector<uint8_t> qhit;
+            for (size_t i0 = 0; i0 < n; i0 += chunkItems) {
+                const size_t i1 = std::min(n, i0 + chunkItems);
+                qr.clear();
+                lightT.clear();
+                slot.clear();
+                for (size_t i = i0; i < i1; i++) {
+                    if (!hit[i]) continue;
+                    const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
+                    for (size_t l = 0; l < SL; l++) {
+                        const SphericalLight& spherical = scene.sphericalLight[l];
+                        for (uint32_t k = 0; k < S; k++) {
+                            const vec3 randomPointOnSphere = spherical.position + spherical.radius * sampler->draw(pixel[i], (uint32_t)level, (uint32_t)l, k);
+                            Ray newRay;  // :178, members in declaration order
+                            newRay.origin = pointOn + (float)(0.001) * cgrt::normalize(randomPointOnSphere - pointOn);
+                            newRay.direction = cgrt::normalize(randomPointOnSphere - pointOn);
+                            newRay.t = cgrt::length(newRay.origin - randomPointOnSphere);
+                            qr.push_back(newRay);
+                            lightT.push_back(cgrt::length(newRay.origin - randomPointOnSphere));
+                            slot.push_back((uint32_t)(i * SL + l));
+                        }
+                    }
+                }
+                qh.assign(qr.size(), HitInfo{});
+                qhit.assign(qr.size(), 0);
+                auto t0 = Clock::now();
+                bvh.intersectBatch(qr.data(), qh.data(), qhit.data(), qr.size());
+                st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
+                st.softShadow += qr.size();
+                for (size_t q = 0; q < qr.size(); q++)
+                    if (!qhit[q] || qr[q].t > lightT[q]) litCount[slot[q]]++;  // :183-199
+            }
+        }
         // ---- direct light (shading, main.cpp:219-232) + reflection rays (shade, :241-264) ----
         std::vector<Ray> nrays;
-        std::vector<uint32_t> nparent;
+        std::vector<uint32_t> nparent, npixel;
         size_t s = 0;
         for (size_t i = 0; i < n; i++) {
             LevelItem& it = items[i];
@@ -97,6 +178,16 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
             if (!it.hit) continue;
             const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
             vec3 result(0.0f);
+            for (size_t l = 0; l < SL; l++) {  // spherical lights first (:168)
+                const PointLight light{scene.sphericalLight[l].position, scene.sphericalLight[l].color};
+                const vec3 fromPosToLight = cgrt::normalize(light.position - pointOn);
+                const vec3 diffuse = diffuseOneLight(light, fromPosToLight, his[i]);
+                const vec3 specular = specularOneLight(rays[i], light, fromPosToLight, his[i]);
+                // softShadowCounter: `samples` exact additions of 1.0f, then the division (:200)
+                const float softShadowCounter = (float)litCount[i * SL + l] / (float)sampler->samples;
+                result += diffuse * softShadowCounter;
+                result += specular * softShadowCounter;
+            }
             for (size_t l = 0; l < L; l++, s++) {
                 const PointLight& light = scene.pointLights[l];
                 const vec3 fromPosToLight = cgrt::normalize(light.position - pointOn);
@@ -115,10 +206,12 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
             it.child = (int)nrays.size();
             nrays.push_back(rr);
             nparent.push_back((uint32_t)i);
+            npixel.push_back(pixel[i]);
         }
         levels.push_back(std::move(items));
         rays = std::move(nrays);
         parent = std::move(nparent);
+        pixel = std::move(npixel);
         his.assign(rays.size(), HitInfo{});
         hit.assign(rays.size(), 0);
         if (!rays.empty()) {
@@ -154,10 +247,11 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
     return st;
 }
 
-RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel) {
+RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel,
+                             const SoftShadowSampler* sampler) {
     const int W = screen.width(), H = screen.height();
     std::vector<float> rgb((size_t)W * H * 3);
-    RenderStats st = renderToBuffer(scene, camera, bvh, W, H, rgb.data(), maxLevel);
+    RenderStats st = renderToBuffer(scene, camera, bvh, W, H, rgb.data(), maxLevel, sampler);
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const float* p = &rgb[3 * ((size_t)y * W + x)];

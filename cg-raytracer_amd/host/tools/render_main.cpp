@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
         if (what == "triangle") scene = loadScene(SingleTriangle, dataDir);
         else if (what == "cube") scene = loadScene(Cube, dataDir);
         else if (what == "cornell") scene = loadScene(CornellBox, dataDir);
+        else if (what == "cornell-spherical") scene = loadScene(CornellBoxSphericalLight, dataDir);
         else if (what == "monkey") scene = loadScene(Monkey, dataDir);
         else if (what == "dragon") scene = loadScene(Dragon, dataDir);
         else if (what == "custom") scene = loadScene(Custom, dataDir);
@@ -41,7 +42,7 @@ int main(int argc, char** argv) {
         const auto end = std::chrono::high_resolution_clock::now();
         std::cout << "Time to render image: " << std::chrono::duration<float, std::milli>(end - start).count() << " milliseconds" << std::endl;
         std::cout << "BVH levels " << bvh.numLevels() << "; rays: " << st.primary << " primary, " << st.shadow << " shadow, " << st.reflection
-                  << " reflection; device share " << st.seconds_device << " s" << std::endl;
+                  << " reflection, " << st.softShadow << " soft-shadow; device share " << st.seconds_device << " s" << std::endl;
         screen.writeBitmapToFile(out);
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;

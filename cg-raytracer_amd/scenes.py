@@ -223,6 +223,12 @@ PRESETS = {
 }
 
 
+# SceneType::CornellBoxSphericalLight (src/scene.cpp:27-32): the Cornell box lit by ONE spherical light {position,
+# radius, color} and no point light; sampled with 200 shadow rays per hit (main.cpp:176).
+CORNELL_SPHERICAL_LIGHTS = np.asarray([[0.0, 0.45, 0.0, 0.1, 1.0, 1.0, 1.0]], F32)
+SOFT_SHADOW_SAMPLES = 200
+
+
 def load_preset(name: str, data_dir: str) -> SceneData:
     fn, norm, lights = PRESETS[name]
     sd = load_obj(os.path.join(data_dir, fn), normalize=norm)

@@ -140,9 +140,30 @@ typedef struct CgrtRenderStats {
     uint64_t primary_rays, shadow_rays, reflection_rays; /* rays that exist upstream (null rays of dead paths not counted) */
     int32_t levels;                                      /* recursion levels actually evaluated */
     float device_ms;                                     /* HIP-event time of all kernels of the frame */
+    uint64_t soft_shadow_rays;                           /* samples towards spherical lights (cgrt_render_soft) */
 } CgrtRenderStats;
 int cgrt_render(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level,
                 float* rgb, CgrtRenderStats* stats);
+
+/* The same frame with the spherical lights of `shading` (src/main.cpp:168-218): per hit and light, `samples` shadow rays
+ * (200 upstream, :176) towards position + radius * randomUnitVector(); the light's diffuse and specular terms are scaled
+ * by the fraction that reaches it (!intersect || ray.t > lightT, :183-199); spherical lights are accumulated before the
+ * point lights (:168, :219).  Upstream draws randomUnitVector() from std::random_device (:46-59), which cannot be
+ * reproduced by anyone; here the draws are DATA: `unit_vectors` holds nunits x 3 floats (normalised gaussian triples
+ * give upstream's distribution) and sample `smp` of spherical light `l` at pixel p = y*W+x, recursion level `lv`, uses
+ * entry  mix(mix(mix(mix(seed ^ 0x9e3779b9) ^ p) ^ (lv * 0x01000193 + l)) ^ smp) % nunits,  mix = murmur3's 32-bit
+ * finaliser (h ^= h>>16; h *= 0x85ebca6b; h ^= h>>13; h *= 0xc2b2ae35; h ^= h>>16).  With the same table and seed the
+ * frame is reproducible to the RGB parity bar; with another table it agrees statistically.
+ * closest_hit = 0: a sample ray stops at the first leaf that accepts a triangle (the count needs the hit flag only and
+ * that flag is the reference's); 1: full closest-hit walk, for checking that claim. */
+typedef struct CgrtSoftShadows {
+    const float* spherical;    /* nspherical x 7 {position, radius, color} (SphericalLight, scene.h:47-51) */
+    const float* unit_vectors; /* nunits x 3 */
+    uint32_t nspherical, samples, nunits, seed;
+    int32_t closest_hit;
+} CgrtSoftShadows;
+int cgrt_render_soft(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
+                     const CgrtSoftShadows* soft, int max_level, float* rgb, CgrtRenderStats* stats);
 
 /* Work counters of the same traversal (separate instrumented launch; not part of any timed region). */
 int cgrt_count_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,

@@ -509,16 +509,43 @@ inline Ray camera_ray(const Camera& c, float px, float py) {  // trackball.cpp:9
 }
 
 // ---------------------------------------------------------------------------
-// Shading + recursion driver (src/main.cpp:61-310), point lights only.
-// Spherical lights use std::random_device (main.cpp:46-59) and are not restated.
+// Shading + recursion driver (src/main.cpp:61-310).
+// Spherical lights (:168-218) draw randomUnitVector() from std::random_device (:46-59): unreproducible upstream, so the
+// draws are a caller-supplied table of unit vectors here and an integer hash of (seed, pixel, level, light, sample)
+// picks the entry -- the rule include/cgrt.h documents for cgrt_render_soft, restated independently below.
 // ---------------------------------------------------------------------------
 struct PointLight {
     V3 pos, color;
 };
+struct SphericalLight {  // scene.h:47-51
+    V3 pos;
+    float radius;
+    V3 color;
+};
+static uint32_t fmix32(uint32_t h) {  // murmur3 32-bit finaliser
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
 struct Shader {
     const Oracle* o;
     std::vector<PointLight> lights;
+    std::vector<SphericalLight> slights;
+    const float* units = nullptr;  // nunits x 3
+    uint32_t nunits = 0, samples = 200, seed = 0;
     int maxLevel = 2;  // main.cpp:267 `level >= 2`
+
+    V3 unit_draw(uint32_t pixel, uint32_t level, uint32_t light, uint32_t smp) const {
+        uint32_t h = fmix32(seed ^ 0x9e3779b9u);
+        h = fmix32(h ^ pixel);
+        h = fmix32(h ^ (level * 0x01000193u + light));
+        h = fmix32(h ^ smp);
+        const float* u = units + 3 * (size_t)(h % nunits);
+        return mk(u[0], u[1], u[2]);
+    }
 
     static V3 material_kd(const Mat& m) { return mk(m.v[0], m.v[1], m.v[2]); }
     static V3 material_ks(const Mat& m) { return mk(m.v[3], m.v[4], m.v[5]); }
@@ -553,9 +580,37 @@ struct Shader {
         return l.color * material_ks(m) * p;
     }
     // main.cpp:160-235 (point-light loop :219-232)
-    V3 shading(const Ray& r, const HitState& h, const Mat& m, uint64_t* nrays) const {
+    V3 shading(const Ray& r, const HitState& h, const Mat& m, uint64_t* nrays, uint32_t pixel, int level) const {
         V3 pointOn = r.o + r.d * r.t;
         V3 res = mk(0, 0, 0);
+        // main.cpp:168-218: spherical lights come first
+        for (size_t li = 0; li < slights.size(); li++) {
+            const SphericalLight& sl = slights[li];
+            PointLight l{sl.pos, sl.color};
+            V3 toLight = normalize3(l.pos - pointOn);
+            V3 dif = diffuse(l, toLight, h, m);
+            V3 spec = specular(r, l, toLight, h, m);
+            float counter = 0.0f;
+            for (uint32_t i = 1; i <= samples; i++) {
+                V3 rp = sl.pos + sl.radius * unit_draw(pixel, (uint32_t)level, (uint32_t)li, i - 1);
+                // :178 aggregate initialisation in member order: origin, direction, then t from the new origin
+                Ray nr;
+                nr.o = pointOn + (float)(0.001) * normalize3(rp - pointOn);
+                nr.d = normalize3(rp - pointOn);
+                nr.t = length3(nr.o - rp);
+                HitState hs{mk(0, 0, 0), -1, 0xffffffffu};
+                float lightT = length3(nr.o - rp);
+                if (nrays) (*nrays)++;
+                if (!o->intersect(nr, hs, nullptr)) {
+                    counter += 1.0f;
+                } else if (nr.t > lightT) {
+                    counter += 1.0f;
+                }
+            }
+            counter = counter / (float)samples;  // :200 `/ 200.0f`
+            res = res + dif * counter;
+            res = res + spec * counter;
+        }
         for (const PointLight& l : lights) {
             V3 toLight = normalize3(l.pos - pointOn);
             if (point_in_shadow(pointOn, l, nrays)) continue;
@@ -565,7 +620,7 @@ struct Shader {
         return res;
     }
     // main.cpp:265-295 trace + :241-264 shade
-    V3 trace(int level, Ray r, uint64_t* nrays) const {
+    V3 trace(int level, Ray r, uint64_t* nrays, uint32_t pixel = 0) const {
         if (level >= maxLevel) return mk(0, 0, 0);
         HitState h{mk(0, 0, 0), -1, 0xffffffffu};
         if (nrays) (*nrays)++;
@@ -574,14 +629,14 @@ struct Shader {
         // uninitialised Material upstream; restated as the default Material (mesh.h:17-23).
         Mat def{{0, 0, 0, 0, 0, 0, 1.0f, 1.0f}};
         const Mat& m = h.material >= 0 ? o->mats[h.material] : def;
-        V3 direct = shading(r, h, m, nrays);
+        V3 direct = shading(r, h, m, nrays, pixel, level);
         // main.cpp:246: comma operator -> only ks.z is tested
         if (m.v[5] <= 0.01f) return direct;
         V3 refl = normalize3(reflect3(r.d, h.normal));
         Ray rr{r.o + r.d * r.t, refl, length3(r.d)};  // :254 note t = |direction| (about 1), not FLT_MAX
         float eps = 0.001;
         rr.o = rr.o + eps * rr.d;
-        V3 rc = trace(level + 1, rr, nrays);
+        V3 rc = trace(level + 1, rr, nrays, pixel);
         return direct + rc * material_ks(m);
     }
 };
@@ -743,11 +798,20 @@ double oracle_trace_primary_timed(void* h, const float* cam, int W, int H, int y
 
 // Full getFinalColor (main.cpp:298-310) per pixel of rows [y0,y1): rgb = 3 floats per pixel (not y-flipped).
 // lights: L x 6 (pos, color).  Returns the number of rays cast.
-uint64_t oracle_render(void* h, const float* cam, int W, int H, int y0, int y1, const float* lights, int nlights,
-                       int maxLevel, float* rgb, int threads) {
+// oracle_render_soft: + spherical lights, S x 7 (pos, radius, color), sampled from the unit-vector table (see Shader).
+uint64_t oracle_render_soft(void* h, const float* cam, int W, int H, int y0, int y1, const float* lights, int nlights,
+                            const float* slights, int nslights, const float* units, uint32_t nunits, uint32_t samples, uint32_t seed,
+                            int maxLevel, float* rgb, int threads) {
     Shader sh;
     sh.o = (const Oracle*)h;
     sh.maxLevel = maxLevel;
+    for (int i = 0; i < nslights; i++)
+        sh.slights.push_back(SphericalLight{mk(slights[7 * i], slights[7 * i + 1], slights[7 * i + 2]), slights[7 * i + 3],
+                                            mk(slights[7 * i + 4], slights[7 * i + 5], slights[7 * i + 6])});
+    sh.units = units;
+    sh.nunits = nunits;
+    sh.samples = samples;
+    sh.seed = seed;
     for (int i = 0; i < nlights; i++)
         sh.lights.push_back(PointLight{mk(lights[6 * i], lights[6 * i + 1], lights[6 * i + 2]),
                                        mk(lights[6 * i + 3], lights[6 * i + 4], lights[6 * i + 5])});
@@ -761,7 +825,7 @@ uint64_t oracle_render(void* h, const float* cam, int W, int H, int y0, int y1, 
         for (int x = 0; x != W; x++) {
             Ray r = camera_ray(c, float(x) / W * 2.0f - 1.0f, float(y) / H * 2.0f - 1.0f);
             uint64_t n = 0;
-            V3 col = sh.trace(0, r, &n);
+            V3 col = sh.trace(0, r, &n, (uint32_t)(y * W + x));
             float* p = rgb + 3 * ((size_t)(y - y0) * W + x);
             p[0] = col.x;
             p[1] = col.y;
@@ -769,6 +833,11 @@ uint64_t oracle_render(void* h, const float* cam, int W, int H, int y0, int y1, 
             total += n;
         }
     return total;
+}
+
+uint64_t oracle_render(void* h, const float* cam, int W, int H, int y0, int y1, const float* lights, int nlights,
+                       int maxLevel, float* rgb, int threads) {
+    return oracle_render_soft(h, cam, W, H, y0, y1, lights, nlights, nullptr, 0, nullptr, 0, 0, 0, maxLevel, rgb, threads);
 }
 
 // ---- primitive intersectors, one call per element (for kernel-level parity tests) ----

@@ -60,6 +60,8 @@ def lib(o0: bool = False) -> C.CDLL:
     L.oracle_trace_primary_timed.restype = C.c_double
     L.oracle_render.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, i32]
     L.oracle_render.restype = u64
+    L.oracle_render_soft.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, C.c_uint32, C.c_uint32, C.c_uint32, i32, vp, i32]
+    L.oracle_render_soft.restype = u64
     for name in ("oracle_ray_triangle", "oracle_ray_plane", "oracle_ray_box", "oracle_ray_sphere"):
         f = getattr(L, name)
         f.argtypes = [vp, vp, u64, vp]
@@ -152,6 +154,19 @@ class OracleScene:
         lights = _f32(lights, (-1, 6))
         rgb = np.zeros(((y1 - y0) * W, 3), np.float32)
         n = int(self.L.oracle_render(self.h, _p(cam), W, H, y0, y1, _p(lights), len(lights), max_level, _p(rgb), threads))
+        return rgb, n
+
+
+    def render_soft(self, cam, W, H, lights, spherical, units, samples=200, seed=0, max_level=2, y0=0, y1=None, threads=0):
+        """main.cpp:168-218 with the randomUnitVector() draws taken from `units` (n x 3), see cgrt_oracle.cpp Shader."""
+        y1 = H if y1 is None else y1
+        cam = _f32(cam, (9,))
+        lights = _f32(lights, (-1, 6))
+        spherical = _f32(spherical, (-1, 7))
+        units = _f32(units, (-1, 3))
+        rgb = np.zeros(((y1 - y0) * W, 3), np.float32)
+        n = int(self.L.oracle_render_soft(self.h, _p(cam), W, H, y0, y1, _p(lights), len(lights), _p(spherical), len(spherical),
+                                          _p(units), len(units), samples, seed, max_level, _p(rgb), threads))
         return rgb, n
 
 

@@ -1,7 +1,7 @@
 """Diagnostic: where do device and oracle bits differ? (run on the GPU box)"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as e
 pkg = e.load_package(); orc = e.load_oracle()
 
