@@ -100,7 +100,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_record_sizes",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
 ]  # fmt: skip
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
     L.cgrt_generate_rays.argtypes = [vp, C.POINTER(Camera)] + [i32] * 6 + [vp]
     L.cgrt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats)]
     L.cgrt_render_soft.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, vp, C.POINTER(RenderStats)]
+    L.cgrt_render_rank.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, i32, i32, vp, C.POINTER(RenderStats)]
     L.cgrt_count_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [C.POINTER(Counters)]
     L.cgrt_count_batch.argtypes = [vp, vp, u64, C.POINTER(Counters)]
     L.cgrt_debug_gather_calibration.argtypes = [i32, u64, i32]
@@ -323,6 +324,21 @@ class Scene:
         q = SoftShadows(spherical.ctypes.data, units.ctypes.data, len(spherical), samples, len(units), seed, int(closest_hit))
         c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
         _check(lib().cgrt_render_soft(self._h, C.byref(c), W, H, _ptr(lights), len(lights), C.byref(q), max_level, _ptr(rgb), C.byref(st)))
+        return rgb, {k: getattr(st, k) for k, _ in st._fields_}
+
+    def render_rank(self, cam, W: int, H: int, rank: int, nranks: int, rgb: Optional[np.ndarray] = None, lights=None, max_level: int = 2,
+                    spherical=None, units=None, samples: int = 200, seed: int = 0):
+        """cgrt_render_rank: this rank's super-tiles of the frame (shading included); other pixels of `rgb` are kept."""
+        lights = _f32(self.sd.point_lights if lights is None else lights, (-1, 6))
+        rgb = np.zeros((W * H, 3), np.float32) if rgb is None else rgb
+        assert rgb.dtype == np.float32 and rgb.size == W * H * 3 and rgb.flags.c_contiguous
+        st = RenderStats()
+        q = None
+        if spherical is not None:
+            spherical, units = _f32(spherical, (-1, 7)), _f32(units, (-1, 3))
+            q = C.byref(SoftShadows(spherical.ctypes.data, units.ctypes.data, len(spherical), samples, len(units), seed, 0))
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_render_rank(self._h, C.byref(c), W, H, _ptr(lights), len(lights), q, max_level, rank, nranks, _ptr(rgb), C.byref(st)))
         return rgb, {k: getattr(st, k) for k, _ in st._fields_}
 
     def generate_rays(self, cam, W: int, H: int, rect=None) -> np.ndarray:

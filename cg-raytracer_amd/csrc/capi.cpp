@@ -3,6 +3,7 @@
 // launches the gfx950 kernels of trace_kernels.hip and fails loudly when no device is usable.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <utility>
@@ -108,6 +109,18 @@ bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nran
     F.nst_rank = (uint32_t)((nst + (uint64_t)nranks - 1 - (uint64_t)rank) / (uint64_t)nranks);
     F.nblocks = ((F.nst_rank + 7u) / 8u) * 8u * 16u;
     return true;
+}
+
+// pixels of the rectangle that belong to F.rank (its super-tiles, clipped)
+unsigned long long owned_pixels(const FrameDev& F) {
+    unsigned long long n = 0;
+    const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
+    for (uint64_t i = (uint64_t)F.rank; i < nst; i += (uint64_t)F.nranks) {
+        const int sx = (int)(i % (uint64_t)F.st_x), sy = (int)(i / (uint64_t)F.st_x);
+        const int w = std::min(64, (F.x1 - F.x0) - 64 * sx), h = std::min(64, (F.y1 - F.y0) - 64 * sy);
+        n += (unsigned long long)w * (unsigned long long)h;
+    }
+    return n;
 }
 
 }  // namespace
@@ -473,7 +486,7 @@ int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters
 // ------------------------------------------------------------------------------------------------
 // renderRayTracing / getFinalColor (src/main.cpp:298-310, :648-720) as a device wavefront
 static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
-                       int max_level, float* rgb, CgrtRenderStats* stats) {
+                       int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats) {
     if (!s || !cam || !rgb || (nlights && !lights)) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     if (W <= 0 || H <= 0 || max_level < 0 || max_level > 16) return fail(CGRT_E_ARG, "bad frame size or recursion depth");
@@ -488,8 +501,8 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     const unsigned L = nlights;
     CgrtRenderStats st{};
     FrameDev F;
-    if (!make_frame(W, H, 0, 0, W, H, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame");
-    const unsigned long long n = (unsigned long long)F.nblocks * 256ull;  // items: the frame in the primary kernel's order
+    if (!make_frame(W, H, 0, 0, W, H, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame or rank");
+    const unsigned long long n = (unsigned long long)F.nblocks * 256ull;  // items: this rank's part of the frame in the primary kernel's order
     DevBuf rays, nrays, hits, normals, srays, shits, sdist, dlights, levels, drgb, dstats, ipix, dslights, dunits, dlit;
     HIP_TRY(ipix.alloc(n * 4));
     HIP_TRY(rays.alloc(n * 28));
@@ -528,7 +541,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
         HIP_TRY(launch_generate_rays_items(C, F, rays.as<float>(), ipix.as<int>(), nullptr));
         HIP_TRY(launch_trace_batch(s->dev, rays.as<float>(), n, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
-        st.primary_rays = npix;
+        st.primary_rays = owned_pixels(F);
         float* cur = rays.as<float>();
         float* nxt = nrays.as<float>();
         for (int level = 0; level < max_level; level++) {
@@ -557,8 +570,9 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             std::swap(cur, nxt);
         }
     }
+    if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data
     if (nlev == 0) {
-        HIP_TRY(hipMemset(drgb.p, 0, npix * 12));
+        if (nranks == 1) HIP_TRY(hipMemset(drgb.p, 0, npix * 12));
     } else {
         HIP_TRY(launch_combine(levels.as<float>(), nlev, n, ipix.as<int>(), drgb.as<float>(), nullptr));
     }
@@ -577,11 +591,15 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
 
 int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level, float* rgb,
                 CgrtRenderStats* stats) {
-    return render_impl(s, cam, W, H, lights, nlights, nullptr, max_level, rgb, stats);
+    return render_impl(s, cam, W, H, lights, nlights, nullptr, max_level, 0, 1, rgb, stats);
 }
 int cgrt_render_soft(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
                      int max_level, float* rgb, CgrtRenderStats* stats) {
-    return render_impl(s, cam, W, H, lights, nlights, soft, max_level, rgb, stats);
+    return render_impl(s, cam, W, H, lights, nlights, soft, max_level, 0, 1, rgb, stats);
+}
+int cgrt_render_rank(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
+                     int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats) {
+    return render_impl(s, cam, W, H, lights, nlights, soft, max_level, rank, nranks, rgb, stats);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -164,6 +164,12 @@ typedef struct CgrtSoftShadows {
 } CgrtSoftShadows;
 int cgrt_render_soft(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
                      const CgrtSoftShadows* soft, int max_level, float* rgb, CgrtRenderStats* stats);
+/* Image tiling across GPUs for whole frames: this call traces and shades only the pixels whose
+ * 64x64 super-tile index % nranks == rank (the ownership rule of cgrt_trace_primary); every secondary ray of a pixel
+ * stays on the GPU that owns the pixel, so ranks exchange nothing.  rgb of pixels owned by other ranks is left as the
+ * caller passed it; the ranks' frames merge by ownership into exactly the single-rank frame.  soft may be NULL. */
+int cgrt_render_rank(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
+                     const CgrtSoftShadows* soft, int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats);
 
 /* Work counters of the same traversal (separate instrumented launch; not part of any timed region). */
 int cgrt_count_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,

@@ -4,7 +4,8 @@ oracle's per-pixel driver timed on a band of rows of the same frame beside it.  
 spherical light: soft shadows over an 800 K-triangle scene."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import __graft_entry__ as e
 pkg = e.load_package()
 orc = e.load_oracle()
@@ -24,7 +25,7 @@ def run(name, sd, sl, W, H, depth, samples, cpu_rows):
         rays = best["primary_rays"] + best["shadow_rays"] + best["reflection_rays"] + best["soft_shadow_rays"]
         print(f"{name} {W}x{H} depth {depth} x{samples} {'closest-hit' if closest else 'any-hit   '}: {best['device_ms']:.2f} ms device, "
               f"{rays} rays ({best['soft_shadow_rays']} soft-shadow samples), {rays / best['device_ms'] / 1e3:.0f} Mrays/s", flush=True)
-    if cpu_rows:
+    if cpu_rows and not os.environ.get("CGRT_NO_CPU"):
         o = orc.OracleScene(sd)
         y0 = H // 2 - cpu_rows // 2
         t0 = time.perf_counter()
@@ -35,7 +36,7 @@ def run(name, sd, sl, W, H, depth, samples, cpu_rows):
               f"-> {dt * H / cpu_rows:.1f} s per frame extrapolated; max |RGB diff| vs device on these rows {err:.2e}", flush=True)
 
 
-cornell = pkg.scenes.SceneData.load("tests/golden/scenes/cornell.npz")
+cornell = pkg.scenes.SceneData.load(os.path.join(ROOT, "tests/golden/scenes/cornell.npz"))
 run("cornell-spherical", cornell, pkg.scenes.CORNELL_SPHERICAL_LIGHTS, 800, 800, 2, 200, 40)
 run("cornell-spherical", cornell, pkg.scenes.CORNELL_SPHERICAL_LIGHTS, 1920, 1080, 2, 200, 54)
 dragon = pkg.scenes.make_dragon(800_000)

@@ -157,3 +157,31 @@ def test_host_mirror_default_sampler_is_statistically_right(pkg, orc, scene_data
     d = np.abs(rgb.astype(np.float64) - ref)
     assert d.mean() < 0.004 and abs(rgb.mean() - ref.mean()) < 0.001
     assert st["soft_shadow"] % 200 == 0 and st["soft_shadow"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_render_rank_frames_merge_into_the_single_rank_frame(pkg, scene_data, nranks):
+    """Whole-frame image tiling across GPUs: each rank shades only its 64x64 super-tiles, keeps every
+    secondary ray of its pixels, and leaves the other pixels alone; merged by ownership the ranks' frames are
+    byte-identical to the single-rank frame (with point lights, a mirror bounce and soft shadows in play)."""
+    sd = scene_data("cornell")
+    W, H = 200, 136  # 4 x 3 super-tiles, ragged on both edges
+    cam = pkg.scenes.default_camera(W, H)
+    units = pkg.unit_vector_table(1024, 2)
+    sl = _soft(pkg)
+    s = pkg.Scene(sd)
+    full, st_full = s.render_soft(cam, W, H, sl, units, samples=8, seed=3, max_level=3)
+    merged = np.full((W * H, 3), -7.0, np.float32)
+    owned = pkg.tiling.owned_mask(W, H, 0, nranks).reshape(-1)
+    tot = dict(primary_rays=0, shadow_rays=0, reflection_rays=0, soft_shadow_rays=0)
+    for r in range(nranks):
+        before = merged.copy()
+        _, st = s.render_rank(cam, W, H, r, nranks, rgb=merged, max_level=3, spherical=sl, units=units, samples=8, seed=3)
+        mine = pkg.tiling.owned_mask(W, H, r, nranks).reshape(-1)
+        assert np.array_equal(merged[~mine], before[~mine])  # other ranks' pixels untouched
+        assert st["primary_rays"] == int(mine.sum())
+        for k in tot:
+            tot[k] += st[k]
+    assert owned.any() and np.array_equal(merged.view(np.uint32), full.view(np.uint32))
+    assert all(tot[k] == st_full[k] for k in tot)
