@@ -53,6 +53,9 @@ namespace cgrt {
 #ifndef CGRT_QUAD_MAX_RAYS
 #define CGRT_QUAD_MAX_RAYS 16
 #endif
+#ifndef CGRT_LEAF_LOOP
+#define CGRT_LEAF_LOOP 0
+#endif
 #ifndef CGRT_STAMP_SUB
 #define CGRT_STAMP_SUB 0  // diagnostic build: in-loop s_memtime stamps of the accelerator node step (load wait vs compute)
 #endif
@@ -190,6 +193,62 @@ __device__ __forceinline__ void test_run(const SceneDev& S, const uint32_t first
 __device__ __forceinline__ uint32_t run_first(const uint32_t r) { return r & 0x03ffffffu; }
 __device__ __forceinline__ uint32_t run_count(const uint32_t r) { return ((r >> 26) & 31u) + 1u; }
 
+// One step through a 128-byte node of the in-leaf accelerator (four child boxes): the nearest hit child becomes `cur`,
+// the other hit children are deferred far-to-near so that they pop near-to-far.  best_t = the scan's running minimum.
+template <bool COUNT>
+__device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P, const float best_t, uint32_t& cur, int& sp,
+                                              uint32_t* __restrict__ stk, LaneCounters& cnt) {
+        if (COUNT) {
+            cnt.sub++;
+            if (first_active_lane()) cnt.w_sub++;
+        }
+        const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
+        const float4 a0 = q[0], b0 = q[1], c0 = q[2];
+        const uint2 m0 = *reinterpret_cast<const uint2*>(q + 3);
+        const float4 a1 = q[4], b1 = q[5], c1 = q[6];
+        const uint2 m1 = *reinterpret_cast<const uint2*>(q + 7);
+        float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
+        slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
+        slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);
+        slab_cons(P, f3(a1.x, a1.y, a1.z), f3(a1.w, b1.x, b1.y), tn2, tf2);
+        slab_cons(P, f3(b1.z, b1.w, c1.x), f3(c1.y, c1.z, c1.w), tn3, tf3);
+        // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
+        // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
+        const float tc = fmaxf(best_t, 0.0f);
+        const float inf = __builtin_inff();
+        // sort key: entry parameter of a hit child, +inf for a missed (or absent: empty box) one
+        float k0 = ((tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc)) ? tn0 : inf;
+        float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
+        float k2 = ((tn2 <= tf2) && (tf2 >= 0.0f) && (tn2 <= tc)) ? tn2 : inf;
+        float k3 = ((tn3 <= tf3) && (tf3 >= 0.0f) && (tn3 <= tc)) ? tn3 : inf;
+        uint32_t r0 = m0.x, r1 = m0.y, r2 = m1.x, r3 = m1.y;
+#define CGRT_CSWAP(ka, ra, kb, rb)          \
+{                                       \
+    const bool sw = kb < ka;            \
+    const float kt = sw ? kb : ka;      \
+    const uint32_t rt = sw ? rb : ra;   \
+    kb = sw ? ka : kb;                  \
+    rb = sw ? ra : rb;                  \
+    ka = kt;                            \
+    ra = rt;                            \
+}
+        CGRT_CSWAP(k0, r0, k1, r1)
+        CGRT_CSWAP(k2, r2, k3, r3)
+        CGRT_CSWAP(k0, r0, k2, r2)
+        CGRT_CSWAP(k1, r1, k3, r3)
+        CGRT_CSWAP(k1, r1, k2, r2)
+#undef CGRT_CSWAP
+        // Branch-free pushes: the slot is always written and only kept (sp advanced) when the child was hit; a
+        // level defers at most three children, so the writes stay inside the lane's SUB_STACK_ENTRIES slots.
+        stk[sp * CGRT_BLOCK] = r3;
+        sp += (k3 < inf) ? 1 : 0;
+        stk[sp * CGRT_BLOCK] = r2;
+        sp += (k2 < inf) ? 1 : 0;
+        stk[sp * CGRT_BLOCK] = r1;
+        sp += (k1 < inf) ? 1 : 0;
+        cur = (k0 < inf) ? r0 : REF_NONE;
+    }
+
 // intersectLeaf (bvh.cpp:535-553) for one ray.  "while-while": lanes first step through accelerator nodes
 // until each stands on a run of triangles (or has nothing left), then the runs are tested together.
 // Stack entries are bare references (carrying the entry parameter for culling on pop was measured: no gain).
@@ -207,62 +266,24 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
     } else if (SUB_WIDTH == 4) {
         int sp = sp0;
         uint32_t cur = LR.sub_root;
-        // One step through a 128-byte node (four child boxes): the nearest hit child becomes `cur`, the other hit
-        // children are deferred far-to-near so that they pop near-to-far.
-        auto node_step = [&]() __attribute__((always_inline)) {
-            if (COUNT) {
-                cnt.sub++;
-                if (first_active_lane()) cnt.w_sub++;
+#if CGRT_LEAF_LOOP == 1
+        // "if-if": every iteration a lane takes at most one node step, then (if it now stands on a run) one run test,
+        // then pops -- lanes never wait for others to finish a whole node phase.
+        while (cur != REF_NONE) {
+            if (!(cur & REF_LEAF)) sub_node_step<COUNT>(S, P, L.best_t, cur, sp, stk, cnt);
+            if (cur != REF_NONE && (cur & REF_LEAF)) {
+                test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, L, cnt);
+                cur = REF_NONE;
             }
-            const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
-            const float4 a0 = q[0], b0 = q[1], c0 = q[2];
-            const uint2 m0 = *reinterpret_cast<const uint2*>(q + 3);
-            const float4 a1 = q[4], b1 = q[5], c1 = q[6];
-            const uint2 m1 = *reinterpret_cast<const uint2*>(q + 7);
-            float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
-            slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
-            slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);
-            slab_cons(P, f3(a1.x, a1.y, a1.z), f3(a1.w, b1.x, b1.y), tn2, tf2);
-            slab_cons(P, f3(b1.z, b1.w, c1.x), f3(c1.y, c1.z, c1.w), tn3, tf3);
-            // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
-            // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
-            const float tc = fmaxf(L.best_t, 0.0f);
-            const float inf = __builtin_inff();
-            // sort key: entry parameter of a hit child, +inf for a missed (or absent: empty box) one
-            float k0 = ((tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc)) ? tn0 : inf;
-            float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
-            float k2 = ((tn2 <= tf2) && (tf2 >= 0.0f) && (tn2 <= tc)) ? tn2 : inf;
-            float k3 = ((tn3 <= tf3) && (tf3 >= 0.0f) && (tn3 <= tc)) ? tn3 : inf;
-            uint32_t r0 = m0.x, r1 = m0.y, r2 = m1.x, r3 = m1.y;
-#define CGRT_CSWAP(ka, ra, kb, rb)          \
-    {                                       \
-        const bool sw = kb < ka;            \
-        const float kt = sw ? kb : ka;      \
-        const uint32_t rt = sw ? rb : ra;   \
-        kb = sw ? ka : kb;                  \
-        rb = sw ? ra : rb;                  \
-        ka = kt;                            \
-        ra = rt;                            \
-    }
-            CGRT_CSWAP(k0, r0, k1, r1)
-            CGRT_CSWAP(k2, r2, k3, r3)
-            CGRT_CSWAP(k0, r0, k2, r2)
-            CGRT_CSWAP(k1, r1, k3, r3)
-            CGRT_CSWAP(k1, r1, k2, r2)
-#undef CGRT_CSWAP
-            // Branch-free pushes: the slot is always written and only kept (sp advanced) when the child was hit; a
-            // level defers at most three children, so the writes stay inside the lane's SUB_STACK_ENTRIES slots.
-            stk[sp * CGRT_BLOCK] = r3;
-            sp += (k3 < inf) ? 1 : 0;
-            stk[sp * CGRT_BLOCK] = r2;
-            sp += (k2 < inf) ? 1 : 0;
-            stk[sp * CGRT_BLOCK] = r1;
-            sp += (k1 < inf) ? 1 : 0;
-            cur = (k0 < inf) ? r0 : REF_NONE;
-        };
+            if (cur == REF_NONE && sp > sp0) {
+                sp -= 1;
+                cur = stk[sp * CGRT_BLOCK];
+            }
+        }
+#else
         for (;;) {
             // ---- node phase ----
-            while (cur != REF_NONE && !(cur & REF_LEAF)) node_step();
+            while (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, P, L.best_t, cur, sp, stk, cnt);
             // ---- triangle phase ----
             if (cur != REF_NONE) test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, L, cnt);
             // ---- pop ----
@@ -270,6 +291,7 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
             sp -= 1;
             cur = stk[sp * CGRT_BLOCK];
         }
+#endif
     } else {
         int sp = sp0;
         uint32_t cur = LR.sub_root;
@@ -442,6 +464,89 @@ __device__ __forceinline__ bool walk_begin(const SceneDev& S, Walk& W) {
     return true;
 }
 
+// intersectNonLeaf (bvh.cpp:715-736) for the inner node `cur`: both child boxes are tested, the child the reference
+// enters first becomes `cur` (REF_NONE if neither is entered), the other one is deferred with its box parameter.
+template <bool COUNT>
+__device__ __forceinline__ void topo_step(const SceneDev& S, const Walk& W, const F3 o, const F3 d, uint32_t& cur, int& sp,
+                                          uint32_t* __restrict__ stk, LaneCounters& cnt) {
+    // intersectNonLeaf, bvh.cpp:715-736
+    if (COUNT) {
+        cnt.inner++;
+        if (first_active_lane()) cnt.w_inner++;
+    }
+    const float4* q = reinterpret_cast<const float4*>(S.packets + cur);
+    const float4 a = q[0], b = q[1], c = q[2];
+    const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
+    const F3 llo = f3(a.x, a.y, a.z), lhi = f3(a.w, b.x, b.y);
+    const F3 rlo = f3(b.z, b.w, c.x), rhi = f3(c.y, c.z, c.w);
+    float tL = -1.0f, tR = -1.0f, tb;
+    bool inL, inR;
+    if (W.R.fd) {
+        if (ray_box_fast(llo, lhi, o, d, W.R, W.t, tb, inL)) tL = tb;
+        if (ray_box_fast(rlo, rhi, o, d, W.R, W.t, tb, inR)) tR = tb;
+    } else {
+        if (ray_box(llo, lhi, o, d, W.t, tb)) tL = tb;
+        if (ray_box(rlo, rhi, o, d, W.t, tb)) tR = tb;
+        inL = starts_in_box(o, llo, lhi);
+        inR = starts_in_box(o, rlo, rhi);
+    }
+    uint32_t first = REF_NONE, second = REF_NONE;
+    float tsec = 0.0f;
+    if (inL && inR) {  // intersectDeeper :685-688, left then right, no culling
+        first = m.x;
+        second = m.y;
+        tsec = -__builtin_inff();
+    } else if (inL) {  // :689-692
+        first = m.x;
+        if (!(tR < 0)) {
+            second = m.y;
+            tsec = tR;
+        }
+    } else if (inR) {  // :693-696
+        first = m.y;
+        if (!(tL < 0)) {
+            second = m.x;
+            tsec = tL;
+        }
+    } else {  // intersectRayThatStartsOutsideBoxes :611-635
+        const bool ml = tL < 0, mr = tR < 0;
+        if (ml && mr) {
+        } else if (ml) {
+            first = m.y;
+        } else if (mr) {
+            first = m.x;
+        } else if (tL < tR) {
+            first = m.x;
+            second = m.y;
+            tsec = tR;
+        } else {
+            first = m.y;
+            second = m.x;
+            tsec = tL;
+        }
+    }
+    // branch-free push: the two slots above sp are always written and only kept when a child was deferred
+    // (at most MAX_LEVELS - 1 deferred children exist at any time, so the slots are inside the lane's slice)
+    stk[sp * CGRT_BLOCK] = second;
+    stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
+    sp += (second != REF_NONE) ? 2 : 0;
+    cur = first;
+}
+
+// Pops deferred children until one is still wanted (bvh.cpp:582: a deferred child is skipped iff ray.t < tSecond).
+__device__ __forceinline__ bool topo_pop(const float t, uint32_t& cur, int& sp, const uint32_t* __restrict__ stk) {
+    while (sp > 0) {
+        sp -= 2;
+        const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
+        const uint32_t r = stk[sp * CGRT_BLOCK];
+        if (!(t < ts)) {
+            cur = r;
+            return true;
+        }
+    }
+    return false;
+}
+
 // Topology phase of a round: intersectNonLeaf steps until the lane stands on a leaf (returns false, W.cur = the leaf)
 // or has nothing left (returns true).
 template <bool COUNT>
@@ -470,68 +575,7 @@ __device__ __forceinline__ bool walk_topology(const SceneDev& S, Walk& W, uint32
             }
         }
         if (cur & REF_LEAF) break;
-        // intersectNonLeaf, bvh.cpp:715-736
-        if (COUNT) {
-            cnt.inner++;
-            if (first_active_lane()) cnt.w_inner++;
-        }
-        const float4* q = reinterpret_cast<const float4*>(S.packets + cur);
-        const float4 a = q[0], b = q[1], c = q[2];
-        const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
-        const F3 llo = f3(a.x, a.y, a.z), lhi = f3(a.w, b.x, b.y);
-        const F3 rlo = f3(b.z, b.w, c.x), rhi = f3(c.y, c.z, c.w);
-        float tL = -1.0f, tR = -1.0f, tb;
-        bool inL, inR;
-        if (W.R.fd) {
-            if (ray_box_fast(llo, lhi, o, d, W.R, W.t, tb, inL)) tL = tb;
-            if (ray_box_fast(rlo, rhi, o, d, W.R, W.t, tb, inR)) tR = tb;
-        } else {
-            if (ray_box(llo, lhi, o, d, W.t, tb)) tL = tb;
-            if (ray_box(rlo, rhi, o, d, W.t, tb)) tR = tb;
-            inL = starts_in_box(o, llo, lhi);
-            inR = starts_in_box(o, rlo, rhi);
-        }
-        uint32_t first = REF_NONE, second = REF_NONE;
-        float tsec = 0.0f;
-        if (inL && inR) {  // intersectDeeper :685-688, left then right, no culling
-            first = m.x;
-            second = m.y;
-            tsec = -__builtin_inff();
-        } else if (inL) {  // :689-692
-            first = m.x;
-            if (!(tR < 0)) {
-                second = m.y;
-                tsec = tR;
-            }
-        } else if (inR) {  // :693-696
-            first = m.y;
-            if (!(tL < 0)) {
-                second = m.x;
-                tsec = tL;
-            }
-        } else {  // intersectRayThatStartsOutsideBoxes :611-635
-            const bool ml = tL < 0, mr = tR < 0;
-            if (ml && mr) {
-            } else if (ml) {
-                first = m.y;
-            } else if (mr) {
-                first = m.x;
-            } else if (tL < tR) {
-                first = m.x;
-                second = m.y;
-                tsec = tR;
-            } else {
-                first = m.y;
-                second = m.x;
-                tsec = tL;
-            }
-        }
-        // branch-free push: the two slots above sp are always written and only kept when a child was deferred
-        // (at most MAX_LEVELS - 1 deferred children exist at any time, so the slots are inside the lane's slice)
-        stk[sp * CGRT_BLOCK] = second;
-        stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
-        sp += (second != REF_NONE) ? 2 : 0;
-        cur = first;
+        topo_step<COUNT>(S, W, o, d, cur, sp, stk, cnt);
     }
     // the lane stands on a leaf
     W.cur = cur;
@@ -549,6 +593,79 @@ __device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t*
     return false;
 }
 
+#ifndef CGRT_UNIFIED
+#define CGRT_UNIFIED 1  // 0: the while-while rounds of walk_round (measured 7 % slower on the bench frame)
+#endif
+// "One loop" form of the same walk: per iteration a lane takes at most one topology step (pops included), then at most
+// one accelerator node step, then at most one run test, whatever its state asks for -- a lane never waits for the other
+// lanes to finish their topology phase or their leaf before it moves on.  The while-while form (walk_round) runs every
+// phase to completion for all lanes of the wave, which serialises waves whose rays are out of phase: its hardest waves
+// execute 4x the node steps of their hardest ray (profiles/r1_step4_wave_anatomy.txt).  Same steps, same arithmetic,
+// same order per ray; only the interleaving between lanes differs.
+template <bool COUNT, bool ANYHIT>
+__device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, uint32_t* __restrict__ stk, LaneCounters& cnt) {
+    const F3 o = W.o, d = W.d;
+    uint32_t cur = W.cur;      // reference-tree node (topology mode)
+    uint32_t scur = REF_NONE;  // accelerator node or run (leaf mode)
+    int sp = W.sp, sp0 = -1;   // sp0 >= 0: the lane is scanning a leaf whose accelerator stack starts at sp0
+    LeafScan L;
+    L.best_t = W.t;
+    L.best_k = -1;
+    L.best_rec = REF_NONE;
+    L.onp_k = -1;
+    L.onp_rec = REF_NONE;
+    bool done = false;
+    while (!done) {
+        if (sp0 < 0) {
+            // ---- topology mode ----
+            if (cur == REF_NONE && !topo_pop(W.t, cur, sp, stk)) done = true;
+            if (!done && !(cur & REF_LEAF)) topo_step<COUNT>(S, W, o, d, cur, sp, stk, cnt);
+            if (!done && cur != REF_NONE && (cur & REF_LEAF)) {
+                if (COUNT) cnt.leaf++;
+                const LeafRec LR = S.leaves[cur & ~REF_LEAF];
+                L.best_t = W.t;
+                L.best_k = -1;
+                L.best_rec = REF_NONE;
+                L.onp_k = -1;
+                L.onp_rec = REF_NONE;
+                if (LR.sub_root == REF_NONE || !W.P.regular || SUB_WIDTH != 4) {
+                    // leaves without accelerator and rays outside its envelope: the whole leaf at once (scan_leaf)
+                    scan_leaf<COUNT>(S, LR, o, d, W.P, W.t, W.hit_rec, stk, sp, cnt);
+                    if (ANYHIT && W.hit_rec != REF_NONE) done = true;
+                } else {
+                    scur = LR.sub_root;
+                    sp0 = sp;
+                }
+                cur = REF_NONE;
+            }
+        }
+        if (sp0 >= 0) {
+            // ---- leaf mode ----
+            if (scur != REF_NONE && !(scur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, L.best_t, scur, sp, stk, cnt);
+            if (scur != REF_NONE && (scur & REF_LEAF)) {
+                test_run<COUNT>(S, run_first(scur), run_count(scur), o, d, L, cnt);
+                scur = REF_NONE;
+            }
+            if (scur == REF_NONE) {
+                if (sp > sp0) {
+                    sp -= 1;
+                    scur = stk[sp * CGRT_BLOCK];
+                } else {  // leaf finished: commit the scan (intersectLeaf's outcome) and return to the topology
+                    if (L.onp_k >= 0) {
+                        W.t = 0.0f;
+                        W.hit_rec = L.onp_rec;
+                    } else if (L.best_k >= 0) {
+                        W.t = L.best_t;
+                        W.hit_rec = L.best_rec;
+                    }
+                    sp0 = -1;
+                    if (ANYHIT && W.hit_rec != REF_NONE) done = true;
+                }
+            }
+        }
+    }
+}
+
 // ANYHIT: stop after the first leaf that accepted a triangle.  The walk up to there is the reference's, so the hit FLAG
 // is the reference's (some acceptance happens upstream iff one happens in the first leaf that has one); t and the
 // record are those of that leaf, not the final ones.
@@ -559,10 +676,14 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F
     W.o = o;
     W.d = d;
     W.t = t;
+#if CGRT_UNIFIED
+    if (walk_begin(S, W)) walk_tree_unified<COUNT, ANYHIT>(S, W, stk, cnt);
+#else
     if (walk_begin(S, W))
         while (!walk_round<COUNT>(S, W, stk, cnt)) {
             if (ANYHIT && W.hit_rec != REF_NONE) break;
         }
+#endif
     t = W.t;
     hit_rec = W.hit_rec;
 }
