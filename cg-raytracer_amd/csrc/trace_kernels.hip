@@ -596,12 +596,12 @@ __device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t*
 #ifndef CGRT_UNIFIED
 #define CGRT_UNIFIED 1  // 0: the while-while rounds of walk_round (measured 7 % slower on the bench frame)
 #endif
-// "One loop" form of the same walk: per iteration a lane takes at most one topology step (pops included), then at most
-// one accelerator node step, then at most one run test, whatever its state asks for -- a lane never waits for the other
-// lanes to finish their topology phase or their leaf before it moves on.  The while-while form (walk_round) runs every
-// phase to completion for all lanes of the wave, which serialises waves whose rays are out of phase: its hardest waves
-// execute 4x the node steps of their hardest ray (profiles/r1_step4_wave_anatomy.txt).  Same steps, same arithmetic,
-// same order per ray; only the interleaving between lanes differs.
+// "One loop" form of the same walk: an iteration offers every lane, in this order, two topology steps (pops included),
+// the entry into a leaf, two accelerator node steps, one run test and the pop inside the leaf; a lane takes the pieces
+// its state asks for and never waits for the other lanes to finish their topology phase or their leaf.  The while-while
+// form (walk_round) runs every phase to completion for all lanes of the wave, which serialises waves whose rays are out
+// of phase: its hardest waves execute 4x the node steps of their hardest ray (profiles/r1_step4_wave_anatomy.txt).
+// Same steps, same arithmetic, same order per ray; only the interleaving between lanes differs.
 template <bool COUNT, bool ANYHIT>
 __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, uint32_t* __restrict__ stk, LaneCounters& cnt) {
     const F3 o = W.o, d = W.d;
@@ -615,54 +615,63 @@ __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, ui
     L.onp_k = -1;
     L.onp_rec = REF_NONE;
     bool done = false;
-    while (!done) {
-        if (sp0 < 0) {
-            // ---- topology mode ----
+    // The pieces of an iteration; each acts only on lanes whose state asks for it.
+    auto T = [&]() __attribute__((always_inline)) {  // topology: pop if needed, one intersectNonLeaf step
+        if (sp0 < 0 && !done) {
             if (cur == REF_NONE && !topo_pop(W.t, cur, sp, stk)) done = true;
             if (!done && !(cur & REF_LEAF)) topo_step<COUNT>(S, W, o, d, cur, sp, stk, cnt);
-            if (!done && cur != REF_NONE && (cur & REF_LEAF)) {
-                if (COUNT) cnt.leaf++;
-                const LeafRec LR = S.leaves[cur & ~REF_LEAF];
-                L.best_t = W.t;
-                L.best_k = -1;
-                L.best_rec = REF_NONE;
-                L.onp_k = -1;
-                L.onp_rec = REF_NONE;
-                if (LR.sub_root == REF_NONE || !W.P.regular || SUB_WIDTH != 4) {
-                    // leaves without accelerator and rays outside its envelope: the whole leaf at once (scan_leaf)
-                    scan_leaf<COUNT>(S, LR, o, d, W.P, W.t, W.hit_rec, stk, sp, cnt);
-                    if (ANYHIT && W.hit_rec != REF_NONE) done = true;
-                } else {
-                    scur = LR.sub_root;
-                    sp0 = sp;
+        }
+    };
+    auto E = [&]() __attribute__((always_inline)) {  // enter the leaf the lane stands on
+        if (sp0 < 0 && !done && cur != REF_NONE && (cur & REF_LEAF)) {
+            if (COUNT) cnt.leaf++;
+            const LeafRec LR = S.leaves[cur & ~REF_LEAF];
+            L.best_t = W.t;
+            L.best_k = -1;
+            L.best_rec = REF_NONE;
+            L.onp_k = -1;
+            L.onp_rec = REF_NONE;
+            if (LR.sub_root == REF_NONE || !W.P.regular || SUB_WIDTH != 4) {
+                // leaves without accelerator and rays outside its envelope: the whole leaf at once (scan_leaf)
+                scan_leaf<COUNT>(S, LR, o, d, W.P, W.t, W.hit_rec, stk, sp, cnt);
+                if (ANYHIT && W.hit_rec != REF_NONE) done = true;
+            } else {
+                scur = LR.sub_root;
+                sp0 = sp;
+            }
+            cur = REF_NONE;
+        }
+    };
+    auto N = [&]() __attribute__((always_inline)) {  // one accelerator node step
+        if (sp0 >= 0 && scur != REF_NONE && !(scur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, L.best_t, scur, sp, stk, cnt);
+    };
+    auto R = [&]() __attribute__((always_inline)) {  // one run of triangles
+        if (sp0 >= 0 && scur != REF_NONE && (scur & REF_LEAF)) {
+            test_run<COUNT>(S, run_first(scur), run_count(scur), o, d, L, cnt);
+            scur = REF_NONE;
+        }
+    };
+    auto P = [&]() __attribute__((always_inline)) {  // next deferred child of the leaf, or the leaf is finished
+        if (sp0 >= 0 && scur == REF_NONE) {
+            if (sp > sp0) {
+                sp -= 1;
+                scur = stk[sp * CGRT_BLOCK];
+            } else {  // commit the scan (intersectLeaf's outcome) and return to the topology
+                if (L.onp_k >= 0) {
+                    W.t = 0.0f;
+                    W.hit_rec = L.onp_rec;
+                } else if (L.best_k >= 0) {
+                    W.t = L.best_t;
+                    W.hit_rec = L.best_rec;
                 }
-                cur = REF_NONE;
+                sp0 = -1;
+                if (ANYHIT && W.hit_rec != REF_NONE) done = true;
             }
         }
-        if (sp0 >= 0) {
-            // ---- leaf mode ----
-            if (scur != REF_NONE && !(scur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, L.best_t, scur, sp, stk, cnt);
-            if (scur != REF_NONE && (scur & REF_LEAF)) {
-                test_run<COUNT>(S, run_first(scur), run_count(scur), o, d, L, cnt);
-                scur = REF_NONE;
-            }
-            if (scur == REF_NONE) {
-                if (sp > sp0) {
-                    sp -= 1;
-                    scur = stk[sp * CGRT_BLOCK];
-                } else {  // leaf finished: commit the scan (intersectLeaf's outcome) and return to the topology
-                    if (L.onp_k >= 0) {
-                        W.t = 0.0f;
-                        W.hit_rec = L.onp_rec;
-                    } else if (L.best_k >= 0) {
-                        W.t = L.best_t;
-                        W.hit_rec = L.best_rec;
-                    }
-                    sp0 = -1;
-                    if (ANYHIT && W.hit_rec != REF_NONE) done = true;
-                }
-            }
-        }
+    };
+    while (!done) {
+        // (sequences with more or fewer pieces per iteration measured slower: profiles/r1_exp_one_loop.txt)
+        T(); T(); E(); N(); N(); R(); P();
     }
 }
 
