@@ -490,41 +490,18 @@ __device__ __forceinline__ void topo_step(const SceneDev& S, const Walk& W, cons
         inL = starts_in_box(o, llo, lhi);
         inR = starts_in_box(o, rlo, rhi);
     }
-    uint32_t first = REF_NONE, second = REF_NONE;
-    float tsec = 0.0f;
-    if (inL && inR) {  // intersectDeeper :685-688, left then right, no culling
-        first = m.x;
-        second = m.y;
-        tsec = -__builtin_inff();
-    } else if (inL) {  // :689-692
-        first = m.x;
-        if (!(tR < 0)) {
-            second = m.y;
-            tsec = tR;
-        }
-    } else if (inR) {  // :693-696
-        first = m.y;
-        if (!(tL < 0)) {
-            second = m.x;
-            tsec = tL;
-        }
-    } else {  // intersectRayThatStartsOutsideBoxes :611-635
-        const bool ml = tL < 0, mr = tR < 0;
-        if (ml && mr) {
-        } else if (ml) {
-            first = m.y;
-        } else if (mr) {
-            first = m.x;
-        } else if (tL < tR) {
-            first = m.x;
-            second = m.y;
-            tsec = tR;
-        } else {
-            first = m.y;
-            second = m.x;
-            tsec = tL;
-        }
-    }
+    // Which child is entered first, which one is deferred (bvh.cpp:679-701 intersectDeeper, :611-635
+    // intersectRayThatStartsOutsideBoxes), as selects:
+    //   a child is visited iff the origin is strictly inside its box or its box test succeeded (not the -1 sentinel);
+    //   left goes first when the origin is inside it (:685-692), or -- origin inside neither -- when only left was hit
+    //   or both were and tL < tR (:626-633); the deferred child carries its own box parameter as tSecond, except when
+    //   the origin is inside both boxes: then right is visited unconditionally (:685-688), i.e. tSecond = -inf.
+    const bool hitL = !(tL < 0), hitR = !(tR < 0);
+    const bool wantL = inL || hitL, wantR = inR || hitR;
+    const bool lfirst = wantL && (inL || !wantR || (!inR && tL < tR));
+    const uint32_t first = lfirst ? m.x : (wantR ? m.y : REF_NONE);
+    const uint32_t second = (wantL && wantR) ? (lfirst ? m.y : m.x) : REF_NONE;
+    const float tsec = (inL && inR) ? -__builtin_inff() : (lfirst ? tR : tL);
     // branch-free push: the two slots above sp are always written and only kept when a child was deferred
     // (at most MAX_LEVELS - 1 deferred children exist at any time, so the slots are inside the lane's slice)
     stk[sp * CGRT_BLOCK] = second;
@@ -671,7 +648,22 @@ __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, ui
     };
     while (!done) {
         // (sequences with more or fewer pieces per iteration measured slower: profiles/r1_exp_one_loop.txt)
+#if CGRT_STAMP_SUB
+        const unsigned long long s0 = stamp_now();
+        T(); T(); E();
+        const unsigned long long s1 = stamp_now();
+        N(); N();
+        const unsigned long long s2 = stamp_now();
+        R(); P();
+        const unsigned long long s3 = stamp_now();
+        if (COUNT && first_active_lane()) {
+            cnt.c_wait += s1 - s0;  // topology pieces
+            cnt.c_comp += s2 - s1;  // node steps
+            cnt.c_tri += s3 - s2;   // run test + pop
+        }
+#else
         T(); T(); E(); N(); N(); R(); P();
+#endif
     }
 }
 

@@ -42,6 +42,11 @@ coef, *_ = np.linalg.lstsq(A, dur[m].astype(np.float64), rcond=None)
 print("least-squares cycles per wave-iteration: inner %.0f sub %.0f tri %.0f const %.0f" % tuple(coef))
 
 if os.environ.get("STAMP_SUB"):
-    for i in order[:6]:
-        print(int(i), "cycles", int(dur[i]), "node-step load wait", int(t[i, 12]), "node-step compute", int(t[i, 13]), "tri phase", int(t[i, 14]),
-              "per sub wave-iter: wait %.0f comp %.0f; per tri wave-iter %.0f" % (t[i, 12] / max(1, t[i, 9]), t[i, 13] / max(1, t[i, 9]), t[i, 14] / max(1, t[i, 10])))
+    # CGRT_STAMP_SUB build with the one-loop walk: columns 12..14 = wave cycles inside the topology pieces (T T E), the
+    # node steps (N N) and the run test + pop (R P); wave-iteration counts of the bodies in columns 8..10
+    for i in order[:8]:
+        print(int(i), "cycles", int(dur[i]), "topology pieces", int(t[i, 12]), "node steps", int(t[i, 13]), "run+pop", int(t[i, 14]),
+              "| per executed body: topology %.0f node %.0f run %.0f" % (t[i, 12] / max(1, t[i, 8]), t[i, 13] / max(1, t[i, 9]), t[i, 14] / max(1, t[i, 10])))
+    tot3 = t[hv, 12:15].sum(0)
+    print("all heavy waves: topology %.3g node %.3g run+pop %.3g cycles; per executed body %.0f %.0f %.0f" %
+          (tot3[0], tot3[1], tot3[2], tot3[0] / tot[4], tot3[1] / tot[5], tot3[2] / max(1, tot[6])))
