@@ -488,6 +488,22 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
             if (*r != REF_NONE) *r += (*r & REF_LEAF) ? out.tri_base : out.sub_base;
     out.root_box = out.nodes[0].box;
     out.root_ref = ref_of(0);
+    if (SUB_WIDTH == 4 && !out.subnodes.empty()) {
+        // accelerated leaves are referenced by their accelerator root (cgrt_layout.h REF_LEAF_ACCEL)
+        auto direct = [&](uint32_t r) -> uint32_t {
+            if (r == REF_NONE || !(r & REF_LEAF)) return r;
+            const uint32_t li = r & ~REF_LEAF;
+            const uint32_t root = out.leaves[li].sub_root;
+            if (root == REF_NONE) return r;
+            out.subnodes[root - out.sub_base].pad[0] = li;
+            return REF_LEAF | REF_LEAF_ACCEL | root;
+        };
+        for (NodePacket& P : out.packets) {
+            P.left = direct(P.left);
+            P.right = direct(P.right);
+        }
+        out.root_ref = direct(out.root_ref);
+    }
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     return true;
 }

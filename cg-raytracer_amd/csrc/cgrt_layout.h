@@ -8,6 +8,11 @@ namespace cgrt {
 // table; clear -> index of the inner node's NodePacket.
 static const uint32_t REF_LEAF = 0x80000000u;
 static const uint32_t REF_NONE = 0xffffffffu;
+// A leaf with an in-leaf accelerator is referenced by the accelerator's root directly: REF_LEAF | REF_LEAF_ACCEL | index
+// of the root SubNode in the record array (26 bits), so that entering the leaf needs no LeafRec load; the leaf-table
+// index of such a leaf is kept in its root SubNode's pad[0] for the paths that want first/count (linear scan).
+static const uint32_t REF_LEAF_ACCEL = 0x40000000u;
+static const uint32_t REF_INDEX26 = 0x03ffffffu;
 static const int MAX_LEVELS = 12;  // bvh.cpp:48 maxDepth; per-ray stack never exceeds MAX_LEVELS - 1
 
 // One inner node of the reference tree with BOTH child boxes (64 B, one cache-line half): the two

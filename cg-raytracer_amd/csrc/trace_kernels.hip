@@ -524,6 +524,12 @@ __device__ __forceinline__ bool topo_pop(const float t, uint32_t& cur, int& sp, 
     return false;
 }
 
+// LeafRec of a leaf reference in either encoding (cgrt_layout.h REF_LEAF_ACCEL).
+__device__ __forceinline__ LeafRec leaf_rec_of(const SceneDev& S, const uint32_t ref) {
+    const uint32_t li = (ref & REF_LEAF_ACCEL) ? S.subnodes[ref & REF_INDEX26].pad[0] : (ref & ~REF_LEAF);
+    return S.leaves[li];
+}
+
 // Topology phase of a round: intersectNonLeaf steps until the lane stands on a leaf (returns false, W.cur = the leaf)
 // or has nothing left (returns true).
 template <bool COUNT>
@@ -565,7 +571,7 @@ __device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t*
     if (walk_topology<COUNT>(S, W, stk, cnt)) return true;
     // ---- leaf phase ----
     if (COUNT) cnt.leaf++;
-    scan_leaf<COUNT>(S, S.leaves[W.cur & ~REF_LEAF], W.o, W.d, W.P, W.t, W.hit_rec, stk, W.sp, cnt);
+    scan_leaf<COUNT>(S, leaf_rec_of(S, W.cur), W.o, W.d, W.P, W.t, W.hit_rec, stk, W.sp, cnt);
     W.cur = REF_NONE;
     return false;
 }
@@ -602,18 +608,17 @@ __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, ui
     auto E = [&]() __attribute__((always_inline)) {  // enter the leaf the lane stands on
         if (sp0 < 0 && !done && cur != REF_NONE && (cur & REF_LEAF)) {
             if (COUNT) cnt.leaf++;
-            const LeafRec LR = S.leaves[cur & ~REF_LEAF];
             L.best_t = W.t;
             L.best_k = -1;
             L.best_rec = REF_NONE;
             L.onp_k = -1;
             L.onp_rec = REF_NONE;
-            if (LR.sub_root == REF_NONE || !W.P.regular || SUB_WIDTH != 4) {
+            if (!(cur & REF_LEAF_ACCEL) || !W.P.regular || SUB_WIDTH != 4) {
                 // leaves without accelerator and rays outside its envelope: the whole leaf at once (scan_leaf)
-                scan_leaf<COUNT>(S, LR, o, d, W.P, W.t, W.hit_rec, stk, sp, cnt);
+                scan_leaf<COUNT>(S, leaf_rec_of(S, cur), o, d, W.P, W.t, W.hit_rec, stk, sp, cnt);
                 if (ANYHIT && W.hit_rec != REF_NONE) done = true;
-            } else {
-                scur = LR.sub_root;
+            } else {  // the reference IS the accelerator's root: nothing to load
+                scur = cur & REF_INDEX26;
                 sp0 = sp;
             }
             cur = REF_NONE;
@@ -998,7 +1003,7 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
             LR.sub_root = REF_NONE;
             LR.pad = 0;
             if (at_leaf) {
-                LR = S.leaves[W.cur & ~REF_LEAF];
+                LR = leaf_rec_of(S, W.cur);
                 if (COUNT || STAMP) cnt.leaf++;
             }
             const bool qok = at_leaf && (LR.sub_root != REF_NONE) && W.P.regular && (SUB_WIDTH == 4);
