@@ -178,8 +178,13 @@ __device__ __forceinline__ void test_run(const SceneDev& S, const uint32_t first
     const float4* q = reinterpret_cast<const float4*>(S.tris + first);
     float4 a0 = q[0], b0 = q[1], c0 = q[2], e0 = q[3];
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t j = (i + 1 < n) ? i + 1 : i;
-        const float4 a1 = q[4 * j], b1 = q[4 * j + 1], c1 = q[4 * j + 2], e1 = q[4 * j + 3];
+        float4 a1 = a0, b1 = b0, c1 = c0, e1 = e0;
+        if (i + 1 < n) {  // the next record is requested before this one is evaluated
+            a1 = q[4 * i + 4];
+            b1 = q[4 * i + 5];
+            c1 = q[4 * i + 6];
+            e1 = q[4 * i + 7];
+        }
         if (COUNT && first_active_lane()) cnt.w_tri++;
         test_record(a0, b0, c0, e0, first + i, o, d, L);
         a0 = a1;
@@ -514,8 +519,9 @@ __device__ __forceinline__ void topo_step(const SceneDev& S, const Walk& W, cons
 __device__ __forceinline__ bool topo_pop(const float t, uint32_t& cur, int& sp, const uint32_t* __restrict__ stk) {
     while (sp > 0) {
         sp -= 2;
+        const uint32_t r = stk[sp * CGRT_BLOCK];  // both words in one LDS access (ds_read2st64_b32)
         const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
-        const uint32_t r = stk[sp * CGRT_BLOCK];
+        asm volatile("" : : "v"(r), "v"(ts));  // keeps the pair together: the reference is wanted whenever ts passes
         if (!(t < ts)) {
             cur = r;
             return true;
