@@ -66,6 +66,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 }
 struct LaneCounters {
     unsigned long long c_wait = 0, c_comp = 0, c_tri = 0;  // CGRT_STAMP_SUB only
+    unsigned long long c_piece[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // CGRT_STAMP_SUB, one-loop walk: cycles in T T E N N R P, loop trips
     uint32_t inner = 0, leaf = 0, tri = 0, sub = 0;
     // wave-level iteration counts (diagnostic): in every executed loop body exactly one active lane adds 1,
     // so the sum over lanes is the number of times the WAVE ran that body
@@ -660,17 +661,28 @@ __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, ui
     while (!done) {
         // (sequences with more or fewer pieces per iteration measured slower: profiles/r1_exp_one_loop.txt)
 #if CGRT_STAMP_SUB
-        const unsigned long long s0 = stamp_now();
-        T(); T(); E();
-        const unsigned long long s1 = stamp_now();
-        N(); N();
-        const unsigned long long s2 = stamp_now();
-        R(); P();
-        const unsigned long long s3 = stamp_now();
+        unsigned long long st[8];
+        st[0] = stamp_now();
+        T();
+        st[1] = stamp_now();
+        T();
+        st[2] = stamp_now();
+        E();
+        st[3] = stamp_now();
+        N();
+        st[4] = stamp_now();
+        N();
+        st[5] = stamp_now();
+        R();
+        st[6] = stamp_now();
+        P();
+        st[7] = stamp_now();
         if (COUNT && first_active_lane()) {
-            cnt.c_wait += s1 - s0;  // topology pieces
-            cnt.c_comp += s2 - s1;  // node steps
-            cnt.c_tri += s3 - s2;   // run test + pop
+            for (int k = 0; k < 7; k++) cnt.c_piece[k] += st[k + 1] - st[k];
+            cnt.c_piece[7] += 1;
+            cnt.c_wait += st[3] - st[0];  // topology pieces
+            cnt.c_comp += st[5] - st[3];  // node steps
+            cnt.c_tri += st[7] - st[5];   // run test + pop
         }
 #else
         T(); T(); E(); N(); N(); R(); P();
@@ -1043,6 +1055,11 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
             }
 #if CGRT_STAMP_SUB
         unsigned long long cw[3] = {cnt.c_wait, cnt.c_comp, cnt.c_tri};
+        unsigned long long cp[8];
+        for (int k = 0; k < 8; k++) {
+            cp[k] = cnt.c_piece[k];
+            for (int off = 32; off > 0; off >>= 1) cp[k] += __shfl_down(cp[k], off, 64);
+        }
         for (int k = 0; k < 3; k++)
             for (int off = 32; off > 0; off >>= 1) cw[k] += __shfl_down(cw[k], off, 64);
 #endif
@@ -1058,6 +1075,12 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
             p[12] = cw[0];  // replaces max_leaf: wave-summed cycles waiting for the node record
             p[13] = cw[1];  // replaces max_tri: ... computing the node step
             p[14] = cw[2];  // replaces max_sub: ... in the triangle phase
+            // one-loop walk: cycles per piece T T E N, then N R P and the loop trips in the low/high halves of p[4..7], p[11]
+            for (int k = 0; k < 4; k++) p[4 + k] = cp[k];
+            p[11] = cp[4];
+            p[2] = cp[5];  // (replaces the s_memrealtime pair)
+            p[3] = cp[6];
+            p[15] = nactive | (cp[7] << 8);
 #endif
         }
     } else if (COUNT) {
