@@ -170,6 +170,57 @@ __device__ __forceinline__ void test_record(const float4 a, const float4 b, cons
     L.best_rec = rec;
 }
 
+// The same test in two halves, for runs of one or two records: eval_record does all the arithmetic that does not depend
+// on the scan state (no early exits, so the two records of a run interleave and their loads overlap), apply_eval then
+// applies intersectRayWithPlane's rejections and the scan rule in order.  Same expressions, same comparisons.
+struct TriEval {
+    float tt;
+    int k;
+    bool onp, den_ok, inside;
+};
+__device__ __forceinline__ TriEval eval_record(const float4 a, const float4 b, const float4 c, const float4 e, const F3 o, const F3 d) {
+    const F3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.w, b.x, b.y), v2 = f3(b.z, b.w, c.x);
+    const F3 n = f3(c.y, c.z, c.w);
+    const float D = e.x;
+    TriEval E;
+    E.k = (int)__float_as_uint(e.w);
+    const float on = dot(o, n);
+    E.onp = (on == D);
+    const float den = dot(d, n);
+    E.den_ok = !(den == 0);
+    const float q = (D - on) / den;
+    E.tt = E.onp ? 0.0f : q;  // ray_tracing.cpp:43-47: origin on the plane -> t = 0
+    const F3 p = add(o, scale(d, E.tt));
+    E.inside = point_in_triangle(v0, v1, v2, n, p);
+    return E;
+}
+__device__ __forceinline__ void apply_eval(const TriEval& E, const uint32_t rec, LeafScan& L) {
+    const bool onp_take = E.onp && E.inside && (E.k > L.onp_k);
+    L.onp_k = onp_take ? E.k : L.onp_k;
+    L.onp_rec = onp_take ? rec : L.onp_rec;
+    const bool behind = (E.tt >= L.best_t) && !((E.tt == L.best_t) && (E.k < L.best_k));
+    const bool take = !E.onp && E.den_ok && !(E.tt < 0) && !behind && E.inside;
+    L.best_t = take ? E.tt : L.best_t;
+    L.best_k = take ? E.k : L.best_k;
+    L.best_rec = take ? rec : L.best_rec;
+}
+template <bool COUNT>
+__device__ __forceinline__ void test_pair(const SceneDev& S, const uint32_t first, const uint32_t n, const F3 o, const F3 d, LeafScan& L,
+                                          LaneCounters& cnt) {
+    if (COUNT) {
+        cnt.tri += n;
+        if (first_active_lane()) cnt.w_tri++;
+    }
+    const float4* q = reinterpret_cast<const float4*>(S.tris + first);
+    const uint32_t j = (n > 1) ? 4u : 0u;  // a run of one: the second slot re-reads the first record and is not applied
+    const float4 a0 = q[0], b0 = q[1], c0 = q[2], e0 = q[3];
+    const float4 a1 = q[j], b1 = q[j + 1], c1 = q[j + 2], e1 = q[j + 3];
+    const TriEval E0 = eval_record(a0, b0, c0, e0, o, d);
+    const TriEval E1 = eval_record(a1, b1, c1, e1, o, d);
+    apply_eval(E0, first, L);
+    if (n > 1) apply_eval(E1, first + 1, L);
+}
+
 // Tests records [first, first + n), two loads in flight (the second record's 64 bytes are requested before
 // the first one is evaluated; a run is 1..32 contiguous records).
 template <bool COUNT>
@@ -583,6 +634,9 @@ __device__ __forceinline__ bool walk_round(const SceneDev& S, Walk& W, uint32_t*
     return false;
 }
 
+#ifndef CGRT_PAIR
+#define CGRT_PAIR 1  // runs of one or two records through test_pair (+1 %)
+#endif
 #ifndef CGRT_UNIFIED
 #define CGRT_UNIFIED 1  // 0: the while-while rounds of walk_round (measured 7 % slower on the bench frame)
 #endif
@@ -636,7 +690,12 @@ __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, ui
     };
     auto R = [&]() __attribute__((always_inline)) {  // one run of triangles
         if (sp0 >= 0 && scur != REF_NONE && (scur & REF_LEAF)) {
-            test_run<COUNT>(S, run_first(scur), run_count(scur), o, d, L, cnt);
+#if CGRT_PAIR
+            if (SUB_LEAF_TRIS <= 2 && run_count(scur) <= 2)
+                test_pair<COUNT>(S, run_first(scur), run_count(scur), o, d, L, cnt);
+            else
+#endif
+                test_run<COUNT>(S, run_first(scur), run_count(scur), o, d, L, cnt);
             scur = REF_NONE;
         }
     };
