@@ -100,7 +100,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_record_sizes",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
 ]  # fmt: skip
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
         f.argtypes = [vp]
     L.cgrt_set_leaf_accel.argtypes = [i32, i32]
     L.cgrt_num_subnodes.argtypes = [vp]
+    L.cgrt_debug_check_layout.argtypes = [vp]
     L.cgrt_set_primary_mode.argtypes = [i32]
     L.cgrt_get_nodes.argtypes = [vp, vp, vp]
     L.cgrt_leaf_prims.argtypes = [vp, i32, vp, u32]
@@ -302,6 +303,10 @@ class Scene:
                 C.c_void_p(stream) if stream else None,
             )
         )  # fmt: skip
+
+    def check_layout(self) -> None:
+        """cgrt_debug_check_layout: raises when a reference of the record arrays is inconsistent."""
+        _check(lib().cgrt_debug_check_layout(self._h))
 
     def render(self, cam, W: int, H: int, lights=None, max_level: int = 2):
         """cgrt_render: the whole shading/recursion driver on the device. Returns (rgb[W*H,3], stats dict)."""

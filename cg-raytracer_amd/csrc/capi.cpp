@@ -320,6 +320,77 @@ int64_t cgrt_leaf_prims(const CgrtScene* s, int node, uint32_t* out, uint32_t ca
     return n.count;
 }
 
+// Walks the host copy of the device records and checks every reference: child references of the reference tree, leaf
+// references in both encodings (REF_LEAF_ACCEL), accelerator child references and runs, alignment of 4-wide nodes, and
+// that every triangle is reachable exactly once through the accelerator of its leaf.  0 = consistent.
+int cgrt_debug_check_layout(CgrtScene* s) {
+    if (!s) return fail(CGRT_E_ARG, "NULL scene");
+    const BuiltBvh& B = s->bvh;
+    if (B.packets.empty() && B.leaves.empty()) return CGRT_OK;
+    const uint32_t npk = (uint32_t)B.packets.size(), nsub = (uint32_t)B.subnodes.size(), ntri = (uint32_t)B.tris.size();
+    const uint32_t nleaf = (uint32_t)B.leaves.size();
+    if (B.sub_base != npk || B.tri_base != npk + nsub) return fail(CGRT_E_ARG, "record bases do not match the array sizes");
+    std::vector<uint8_t> leaf_seen(nleaf, 0);
+    std::vector<uint32_t> tri_seen(ntri, 0);
+    auto check_leaf_ref = [&](uint32_t r) -> bool {
+        uint32_t li;
+        if (r & REF_LEAF_ACCEL) {
+            const uint32_t root = r & REF_INDEX26;
+            if (SUB_WIDTH != 4 || root < B.sub_base || root >= B.tri_base || ((root - B.sub_base) & 1u)) return false;
+            li = B.subnodes[root - B.sub_base].pad[0];
+            if (li >= nleaf || B.leaves[li].sub_root != root) return false;
+        } else {
+            li = r & ~REF_LEAF;
+            if (li >= nleaf) return false;
+            if (SUB_WIDTH == 4 && B.leaves[li].sub_root != REF_NONE) return false;  // an accelerated leaf must be referenced directly
+        }
+        if (leaf_seen[li]) return false;  // a tree: every leaf has one parent
+        leaf_seen[li] = 1;
+        return true;
+    };
+    auto check_topo_ref = [&](uint32_t r) -> bool {
+        if (r == REF_NONE) return false;
+        return (r & REF_LEAF) ? check_leaf_ref(r) : (r < npk);
+    };
+    if (!check_topo_ref(B.root_ref)) return fail(CGRT_E_ARG, "bad root reference");
+    const uint32_t real_packets = (uint32_t)(B.nodes.size() - nleaf);
+    for (uint32_t i = 0; i < real_packets; i++)
+        if (!check_topo_ref(B.packets[i].left) || !check_topo_ref(B.packets[i].right)) return fail(CGRT_E_ARG, "bad child reference in a node packet");
+    for (uint32_t li = 0; li < nleaf; li++) {
+        const LeafRec& L = B.leaves[li];
+        if (!leaf_seen[li]) return fail(CGRT_E_ARG, "leaf not referenced by the tree");
+        if (L.first < B.tri_base || (uint64_t)L.first + L.count > (uint64_t)B.tri_base + ntri) return fail(CGRT_E_ARG, "leaf record range");
+        if (L.sub_root == REF_NONE) {
+            for (uint32_t k = 0; k < L.count; k++) tri_seen[L.first - B.tri_base + k]++;
+            continue;
+        }
+        // walk the leaf's accelerator
+        std::vector<uint32_t> todo{L.sub_root};
+        while (!todo.empty()) {
+            const uint32_t r = todo.back();
+            todo.pop_back();
+            if (r == REF_NONE) continue;
+            if (r & REF_LEAF) {
+                const uint32_t first = r & REF_INDEX26, cnt = ((r >> 26) & 31u) + 1u;
+                if (first < L.first || first + cnt > L.first + L.count) return fail(CGRT_E_ARG, "run outside its leaf");
+                for (uint32_t k = 0; k < cnt; k++) tri_seen[first - B.tri_base + k]++;
+                continue;
+            }
+            if (r < B.sub_base || r >= B.tri_base) return fail(CGRT_E_ARG, "accelerator node reference out of range");
+            const uint32_t width_recs = SUB_WIDTH == 4 ? 2u : 1u;
+            if (SUB_WIDTH == 4 && ((r - B.sub_base) & 1u)) return fail(CGRT_E_ARG, "4-wide node not 128-byte aligned");
+            for (uint32_t h = 0; h < width_recs; h++) {
+                const SubNode& N = B.subnodes[r - B.sub_base + h];
+                todo.push_back(N.ref0);
+                todo.push_back(N.ref1);
+            }
+        }
+    }
+    for (uint32_t t = 0; t < ntri; t++)
+        if (tri_seen[t] != 1) return fail(CGRT_E_ARG, "a triangle record is reachable " + std::to_string(tri_seen[t]) + " times");
+    return CGRT_OK;
+}
+
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes) {
     if (node_bytes) *node_bytes = sizeof(NodePacket);
     if (tri_bytes) *tri_bytes = sizeof(TriRecord);

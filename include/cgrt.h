@@ -187,6 +187,9 @@ int cgrt_debug_gather_calibration(int device, uint64_t nrecords, int repeats);
 /* Diagnostic: the kernels' 4-operation exact division (trace_kernels.hip fdiv4) against IEEE a[i] / d[i] on the
  * device; mismatches receives the count, first_bad {a, d, got, expected} of the first one. */
 int cgrt_debug_fastdiv_check(int device, const float* a, const float* d, uint64_t n, uint64_t* mismatches, float* first_bad);
+/* Diagnostic: validates every reference of the scene's record arrays on the host (tree child references, leaf references
+ * in both encodings, accelerator nodes and runs, each triangle reachable exactly once).  Works on host-only scenes. */
+int cgrt_debug_check_layout(CgrtScene* scene);
 /* Bytes of one inner-node record / one triangle record / one in-leaf accelerator node / one result. */
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes);
 

@@ -61,3 +61,20 @@ def test_empty_scene(pkg, orc):
     s = pkg.Scene(sd, device=-1)
     assert s.num_levels() == 1 == orc.OracleScene(sd).num_levels()  # numLevels() of no nodes (bvh.cpp:214-224)
     assert s.nodes()[0].shape == (0, 5)
+
+
+@pytest.mark.parametrize("name,accel,run", [("cube", True, 0), ("monkey", True, 0), ("cornell", True, 0), ("blob", True, 0),
+                                            ("dragon60k", True, 0), ("dragon60k", True, 1), ("dragon60k", True, 5), ("dragon60k", False, 0)])
+def test_record_layout_is_consistent(pkg, scene_data, name, accel, run):
+    """Host-side walk of the device records (cgrt_debug_check_layout): tree references, leaf references in both
+    encodings (an accelerated leaf is referenced by its accelerator root), 128-byte alignment of 4-wide nodes, and every
+    triangle reachable exactly once through its leaf."""
+    sd = pkg.scenes.make_dragon(60_000) if name == "dragon60k" else scene_data(name)
+    pkg.set_leaf_accel(accel, run)
+    try:
+        s = pkg.Scene(sd, device=-1)
+        s.check_layout()
+        if name == "dragon60k":
+            assert (s.num_subnodes() > 0) == accel
+    finally:
+        pkg.set_leaf_accel(True, 0)
