@@ -7,8 +7,8 @@ import __graft_entry__ as e
 pkg = e.load_package()
 W, H = 1920, 1080
 cam = pkg.scenes.default_camera(W, H)
-for name, sd, depth in (("cornell", pkg.scenes.SceneData.load("tests/golden/scenes/cornell.npz"), 4),
-                        ("cornell", pkg.scenes.SceneData.load("tests/golden/scenes/cornell.npz"), 2),
+for name, sd, depth in (("cornell", pkg.scenes.SceneData.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/scenes/cornell.npz")), 4),
+                        ("cornell", pkg.scenes.SceneData.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/scenes/cornell.npz")), 2),
                         ("dragon800k", pkg.scenes.make_dragon(800_000), 2)):
     sc = pkg.Scene(sd)
     best = None
