@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from . import scenes  # noqa: F401  (re-export)
+from . import scenes, tiling  # noqa: F401  (re-export)
 from .scenes import SceneData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

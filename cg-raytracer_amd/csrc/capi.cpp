@@ -574,8 +574,12 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     FrameDev F;
     if (!make_frame(W, H, 0, 0, W, H, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame or rank");
     const unsigned long long n = (unsigned long long)F.nblocks * 256ull;  // items: this rank's part of the frame in the primary kernel's order
-    DevBuf rays, nrays, hits, normals, srays, shits, sdist, dlights, levels, drgb, dstats, ipix, dslights, dunits, dlit;
+    // Level 0 = the n items of the frame; every deeper level is a compact list of mirror rays (at most one per entry of the
+    // level above, so n bounds every list); the shadow list of a level holds at most entries * L rays.
+    DevBuf rays, nrays, hits, normals, srays, shits, sdist, sslot, dlights, levels, drgb, dctr, ipix, pixa, pixb, dslights, dunits, dlit;
     HIP_TRY(ipix.alloc(n * 4));
+    HIP_TRY(pixa.alloc(n * 4));
+    HIP_TRY(pixb.alloc(n * 4));
     HIP_TRY(rays.alloc(n * 28));
     HIP_TRY(nrays.alloc(n * 28));
     HIP_TRY(hits.alloc(n * sizeof(CgrtHit)));
@@ -583,12 +587,12 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     HIP_TRY(srays.alloc(n * L * 28));
     HIP_TRY(shits.alloc(n * L * sizeof(CgrtHit)));
     HIP_TRY(sdist.alloc(n * L * 4));
+    HIP_TRY(sslot.alloc(n * L * 4));
     HIP_TRY(dlights.alloc((size_t)L * 24));
     HIP_TRY(levels.alloc((size_t)(max_level > 0 ? max_level : 1) * n * 32));
     HIP_TRY(drgb.alloc(npix * 12));
-    HIP_TRY(dstats.alloc(4 * sizeof(unsigned long long)));
+    HIP_TRY(dctr.alloc(4 * sizeof(uint32_t)));
     if (L) HIP_TRY(hipMemcpy(dlights.p, lights, (size_t)L * 24, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dstats.p, 0, 4 * sizeof(unsigned long long)));
     SoftDev Q{};
     if (SL) {
         HIP_TRY(dslights.alloc((size_t)SL * 28));
@@ -609,43 +613,58 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, nullptr));
     int nlev = 0;
+    std::vector<unsigned long long> level_count;  // entries per evaluated level
     if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
         HIP_TRY(launch_generate_rays_items(C, F, rays.as<float>(), ipix.as<int>(), nullptr));
         HIP_TRY(launch_trace_batch(s->dev, rays.as<float>(), n, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
         st.primary_rays = owned_pixels(F);
         float* cur = rays.as<float>();
         float* nxt = nrays.as<float>();
+        const int* cur_pix = ipix.as<int>();
+        int* nxt_pix = pixa.as<int>();
+        unsigned long long cnt = n;
+        uint32_t* ctr = dctr.as<uint32_t>();  // {shadow rays appended, mirror rays appended, hits} of the level
         for (int level = 0; level < max_level; level++) {
             const int spawn = level + 1 < max_level;
-            HIP_TRY(launch_spawn_shadow(cur, hits.as<CgrtHitDev>(), n, dlights.as<float>(), L, srays.as<float>(), sdist.as<float>(), nullptr));
-            HIP_TRY(launch_trace_batch(s->dev, srays.as<float>(), n * L, shits.as<CgrtHitDev>(), nullptr, nullptr, nullptr));
+            HIP_TRY(hipMemsetAsync(dctr.p, 0, 4 * sizeof(uint32_t), nullptr));
+            if (L) {
+                HIP_TRY(launch_spawn_shadow(cur, hits.as<CgrtHitDev>(), cnt, dlights.as<float>(), L, srays.as<float>(), sdist.as<float>(),
+                                            sslot.as<int>(), ctr, nullptr));
+                // the grid covers the list's capacity, the kernel stops at the appended count
+                HIP_TRY(launch_trace_batch(s->dev, srays.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, nullptr, nullptr, ctr + 0));
+            }
             if (SL) {
                 Q.level = (uint32_t)level;
-                HIP_TRY(hipMemsetAsync(dlit.p, 0, n * SL * 4, nullptr));
-                HIP_TRY(launch_soft_shadow(s->dev, Q, cur, hits.as<CgrtHitDev>(), ipix.as<int>(), n, dlit.as<uint32_t>(), soft->closest_hit == 0,
-                                           nullptr));
+                HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));
+                HIP_TRY(launch_soft_shadow(s->dev, Q, cur, hits.as<CgrtHitDev>(), cur_pix, cnt, dlit.as<uint32_t>(), soft->closest_hit == 0, nullptr));
             }
-            HIP_TRY(launch_shade(cur, hits.as<CgrtHitDev>(), normals.as<float>(), shits.as<CgrtHitDev>(), sdist.as<float>(), n,
-                                 static_cast<const float*>(s->d_materials), dlights.as<float>(), L, dslights.as<float>(), SL,
-                                 dlit.as<uint32_t>(), Q.samples, spawn, levels.as<float>() + (size_t)level * n * 8, nxt,
-                                 dstats.as<unsigned long long>(), nullptr));
+            HIP_TRY(launch_shade(cur, hits.as<CgrtHitDev>(), normals.as<float>(), cur_pix, shits.as<CgrtHitDev>(), sdist.as<float>(),
+                                 sslot.as<int>(), cnt, static_cast<const float*>(s->d_materials), dlights.as<float>(), L, dslights.as<float>(),
+                                 SL, dlit.as<uint32_t>(), Q.samples, spawn, levels.as<float>() + (size_t)level * n * 8, nxt, nxt_pix, ctr,
+                                 nullptr));
             nlev = level + 1;
-            unsigned long long h[4];
-            HIP_TRY(hipMemcpy(h, dstats.p, sizeof(h), hipMemcpyDeviceToHost));  // also the level's sync point
-            const unsigned long long spawned = h[2] - st.reflection_rays;
-            st.shadow_rays = h[1];
-            st.reflection_rays = h[2];
-            st.soft_shadow_rays = h[3];
-            if (!spawn || spawned == 0) break;
-            HIP_TRY(launch_trace_batch(s->dev, nxt, n, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
+            level_count.push_back(cnt);
+            uint32_t h[4];
+            HIP_TRY(hipMemcpy(h, dctr.p, sizeof(h), hipMemcpyDeviceToHost));  // also the level's sync point
+            st.shadow_rays += h[0];
+            st.reflection_rays += h[1];
+            st.soft_shadow_rays += (uint64_t)h[2] * SL * Q.samples;
+            if (!spawn || h[1] == 0) break;
+            cnt = h[1];
+            HIP_TRY(launch_trace_batch(s->dev, nxt, cnt, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
             std::swap(cur, nxt);
+            cur_pix = nxt_pix;
+            nxt_pix = (nxt_pix == pixa.as<int>()) ? pixb.as<int>() : pixa.as<int>();
         }
     }
     if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data
     if (nlev == 0) {
         if (nranks == 1) HIP_TRY(hipMemset(drgb.p, 0, npix * 12));
     } else {
-        HIP_TRY(launch_combine(levels.as<float>(), nlev, n, ipix.as<int>(), drgb.as<float>(), nullptr));
+        for (int level = nlev - 2; level >= 0; level--)  // color = directColor + reflectedColor * ks (main.cpp:262), deepest level first
+            HIP_TRY(launch_fold(levels.as<float>() + (size_t)level * n * 8, levels.as<float>() + (size_t)(level + 1) * n * 8, level_count[level],
+                                nullptr));
+        HIP_TRY(launch_write_rgb(levels.as<float>(), n, ipix.as<int>(), drgb.as<float>(), nullptr));
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));

@@ -33,8 +33,9 @@ hipError_t launch_trace_primary_persistent(const SceneDev& S, const CameraDev& C
 // diagnostic: stamps = 4 x ntiles_rank u64 {memtime start, end, memrealtime start, end} per wave
 hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits,
                                         unsigned long long* stamps, hipStream_t stream);
+// dcount (optional): device word with the number of rays actually present (<= n, the capacity the grid is sized for)
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
-                              unsigned long long* counters, hipStream_t stream);
+                              unsigned long long* counters, hipStream_t stream, const uint32_t* dcount = nullptr);
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);
 // lit[item * nlights + l] += samples of spherical light l that reach it from item's hit point (zeroed by the caller)
 hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
@@ -42,14 +43,17 @@ hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* 
 
 // frame-ordered primary rays for the shading wavefront: n items = F.nblocks * 256; item_pixels[i] = y*W+x or -1
 hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, float* rays, int* item_pixels, hipStream_t stream);
-// shading wavefront (shade_kernels.hip)
+// shading wavefront (shade_kernels.hip); every level is a compact list of live paths
+// counters: 3 device words {shadow rays appended, mirror rays appended, hits}, zeroed by the caller before each level
 hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsigned long long n, const float* lights, unsigned nlights,
-                               float* srays, float* sdist, hipStream_t s);
-hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
-                        unsigned long long n, const float* materials, const float* lights, unsigned nlights, const float* slights,
-                        unsigned nslights, const uint32_t* lit, unsigned samples, int spawn, float* lvl, float* next_rays,
-                        unsigned long long* stats, hipStream_t s);
-hipError_t launch_combine(const float* levels, int nlevels, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
+                               float* srays, float* sdist, int* sslot, uint32_t* counters, hipStream_t s);
+hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, const CgrtHitDev* shits,
+                        const float* sdist, const int* sslot, unsigned long long n, const float* materials, const float* lights,
+                        unsigned nlights, const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, int spawn, float* lvl,
+                        float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s);
+// colour of level `lvl` entries += colour of their child (level lvl + 1) * ks  (main.cpp:262)
+hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s);
+hipError_t launch_write_rgb(const float* lvl0, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
 hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
                                hipStream_t s);
 hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,

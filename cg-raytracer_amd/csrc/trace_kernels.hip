@@ -1278,12 +1278,17 @@ __global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 }
 
+// dcount (optional): device word holding the number of rays actually present (<= n); the grid covers n.
 template <bool COUNT>
 __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
-                                                            unsigned long long* counters) {
+                                                            unsigned long long* counters, const uint32_t* __restrict__ dcount) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
     const unsigned long long i = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
+    if (dcount) {
+        const unsigned long long present = *dcount;
+        n = present < n ? present : n;
+    }
     const bool active = i < n;
     LaneCounters cnt;
     if (active) {
@@ -1549,13 +1554,13 @@ hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, c
     return hipGetLastError();
 }
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
-                              unsigned long long* counters, hipStream_t stream) {
+                              unsigned long long* counters, hipStream_t stream, const uint32_t* dcount) {
     if (n == 0) return hipSuccess;
     const unsigned blocks = grid_for(n, CGRT_BLOCK);
     if (counters)
-        hipLaunchKernelGGL(k_trace_batch<true>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, rays, n, hits, normals, counters);
+        hipLaunchKernelGGL(k_trace_batch<true>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, rays, n, hits, normals, counters, dcount);
     else
-        hipLaunchKernelGGL(k_trace_batch<false>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, rays, n, hits, normals, counters);
+        hipLaunchKernelGGL(k_trace_batch<false>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, rays, n, hits, normals, counters, dcount);
     return hipGetLastError();
 }
 hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
