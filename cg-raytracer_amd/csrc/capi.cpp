@@ -615,16 +615,21 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     int nlev = 0;
     std::vector<unsigned long long> level_count;  // entries per evaluated level
     if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
-        HIP_TRY(launch_generate_rays_items(C, F, rays.as<float>(), ipix.as<int>(), nullptr));
-        HIP_TRY(launch_trace_batch(s->dev, rays.as<float>(), n, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
+        // level 0 = the primary rays that hit something, straight out of the fused primary kernel (pixels that miss are
+        // black, main.cpp:293, and spawn nothing)
+        uint32_t* ctr = dctr.as<uint32_t>();  // {shadow rays appended, mirror rays appended, hits} of the level; [3] = primary hits
+        HIP_TRY(hipMemsetAsync(dctr.p, 0, 4 * sizeof(uint32_t), nullptr));
+        HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays.as<float>(), hits.as<CgrtHitDev>(), normals.as<float>(), ipix.as<int>(), ctr + 3,
+                                             nullptr));
         st.primary_rays = owned_pixels(F);
+        uint32_t nhit0 = 0;
+        HIP_TRY(hipMemcpy(&nhit0, ctr + 3, sizeof(nhit0), hipMemcpyDeviceToHost));
         float* cur = rays.as<float>();
         float* nxt = nrays.as<float>();
         const int* cur_pix = ipix.as<int>();
         int* nxt_pix = pixa.as<int>();
-        unsigned long long cnt = n;
-        uint32_t* ctr = dctr.as<uint32_t>();  // {shadow rays appended, mirror rays appended, hits} of the level
-        for (int level = 0; level < max_level; level++) {
+        unsigned long long cnt = nhit0;
+        for (int level = 0; level < max_level && cnt > 0; level++) {
             const int spawn = level + 1 < max_level;
             HIP_TRY(hipMemsetAsync(dctr.p, 0, 4 * sizeof(uint32_t), nullptr));
             if (L) {
@@ -658,13 +663,14 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         }
     }
     if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data
-    if (nlev == 0) {
-        if (nranks == 1) HIP_TRY(hipMemset(drgb.p, 0, npix * 12));
+    if (nlev == 0) {  // nothing was hit (or max_level == 0): this rank's pixels are black
+        HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
     } else {
         for (int level = nlev - 2; level >= 0; level--)  // color = directColor + reflectedColor * ks (main.cpp:262), deepest level first
             HIP_TRY(launch_fold(levels.as<float>() + (size_t)level * n * 8, levels.as<float>() + (size_t)(level + 1) * n * 8, level_count[level],
                                 nullptr));
-        HIP_TRY(launch_write_rgb(levels.as<float>(), n, ipix.as<int>(), drgb.as<float>(), nullptr));
+        HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
+        HIP_TRY(launch_write_rgb(levels.as<float>(), level_count[0], ipix.as<int>(), drgb.as<float>(), nullptr));
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));

@@ -20,19 +20,32 @@ namespace cgrt {
 
 __device__ __forceinline__ F3 ldv(const float* p) { return f3(p[0], p[1], p[2]); }
 
-// Wave-aggregated append: lanes with `want` get consecutive indices starting at one atomicAdd of the wave's leader.
-__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, const bool want) {
+// Block-aggregated append: threads with `want` get consecutive indices of the list behind `counter`, ONE atomic per
+// workgroup (same-address atomics serialise at the L2, ~12 ns each: one per wave made these streaming kernels
+// atomic-bound).  Every thread of the block must call it; s_tmp = blockDim.x / 64 + 1 LDS words.
+__device__ __forceinline__ uint32_t block_append(uint32_t* counter, const bool want, uint32_t* s_tmp) {
     const unsigned long long m = __ballot(want);
-    if (m == 0) return 0;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    return base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+    if (lane == 0) s_tmp[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (unsigned k = 0; k < nw; k++) {
+            const uint32_t c = s_tmp[k];
+            s_tmp[k] = tot;
+            tot += c;
+        }
+        s_tmp[nw] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t idx = s_tmp[nw] + s_tmp[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();  // s_tmp is reused by the next call
+    return idx;
 }
+#define CGRT_SHADE_BLOCK 1024
 
 // pointInShadow's ray construction (main.cpp:104-111) for every (hit entry, light), appended to the shadow list.
-__global__ void k_spawn_shadow(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits, unsigned long long n,
+__global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_spawn_shadow(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits, unsigned long long n,
                                const float* __restrict__ lights, unsigned nlights, float* __restrict__ srays, float* __restrict__ sdist,
                                int* __restrict__ sslot, uint32_t* __restrict__ counters) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,8 +57,9 @@ __global__ void k_spawn_shadow(const float* __restrict__ rays, const CgrtHitDev*
         pointOn = add(ldv(r), scale(ldv(r + 3), hits[i].t));
     }
     const float eps = 0.001f;
+    __shared__ uint32_t s_tmp[CGRT_SHADE_BLOCK / 64 + 1];
     for (unsigned l = 0; l < nlights; l++) {
-        const uint32_t idx = wave_append(counters + 0, hit);
+        const uint32_t idx = block_append(counters + 0, hit, s_tmp);
         if (in) sslot[i * nlights + l] = hit ? (int)idx : -1;
         if (!hit) continue;
         const F3 toLight = sub(ldv(lights + 6 * l), pointOn);
@@ -66,7 +80,7 @@ __global__ void k_spawn_shadow(const float* __restrict__ rays, const CgrtHitDev*
 // shading (main.cpp:160-235) + shade (:241-264) for one level.  lvl: per entry {colour.xyz, flags} {ks.xyz, child};
 // flags bit0 = hit; child = index of the mirror ray's entry on the next level, -1 when none was spawned.
 // counters[1] += mirror rays appended, counters[2] += hits.
-__global__ void k_shade(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits, const float* __restrict__ normals,
+__global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_shade(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits, const float* __restrict__ normals,
                         const int* __restrict__ pixels, const CgrtHitDev* __restrict__ shits, const float* __restrict__ sdist,
                         const int* __restrict__ sslot, unsigned long long n, const float* __restrict__ materials,
                         const float* __restrict__ lights, unsigned nlights, const float* __restrict__ slights, unsigned nslights,
@@ -136,7 +150,8 @@ __global__ void k_shade(const float* __restrict__ rays, const CgrtHitDev* __rest
             mt = length(d);  // :254: t = |direction| of the parent ray
         }
     }
-    const uint32_t child = wave_append(counters + 1, wants_mirror);
+    __shared__ uint32_t s_tmp[CGRT_SHADE_BLOCK / 64 + 1];
+    const uint32_t child = block_append(counters + 1, wants_mirror, s_tmp);
     if (wants_mirror) {
         float* q = next_rays + 7ull * child;
         q[0] = mo.x;
@@ -153,8 +168,15 @@ __global__ void k_shade(const float* __restrict__ rays, const CgrtHitDev* __rest
         lvl[2 * i] = out0;
         lvl[2 * i + 1] = out1;
     }
+    // hits of the level: one atomic per workgroup
     const uint32_t h = (uint32_t)__popcll(__ballot(hit));
-    if ((threadIdx.x & 63) == 0 && h) atomicAdd(counters + 2, h);
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (unsigned k = 0; k < (blockDim.x >> 6); k++) tot += s_tmp[k];
+        if (tot) atomicAdd(counters + 2, tot);
+    }
 }
 
 // colour = !hit ? 0 : (ks.z <= 0.01 ? direct : direct + childColour * ks)   (main.cpp:248, :262, :293); the child's
@@ -185,7 +207,8 @@ static inline unsigned grid_for(unsigned long long n, unsigned block) { return (
 hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsigned long long n, const float* lights, unsigned nlights,
                                float* srays, float* sdist, int* sslot, uint32_t* counters, hipStream_t s) {
     if (n && nlights)
-        hipLaunchKernelGGL(k_spawn_shadow, dim3(grid_for(n, 256)), dim3(256), 0, s, rays, hits, n, lights, nlights, srays, sdist, sslot, counters);
+        hipLaunchKernelGGL(k_spawn_shadow, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, n, lights, nlights, srays,
+                           sdist, sslot, counters);
     return hipGetLastError();
 }
 hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, const CgrtHitDev* shits,
@@ -193,7 +216,7 @@ hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* 
                         unsigned nlights, const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, int spawn, float* lvl,
                         float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s) {
     if (n)
-        hipLaunchKernelGGL(k_shade, dim3(grid_for(n, 256)), dim3(256), 0, s, rays, hits, normals, pixels, shits, sdist, sslot, n, materials,
+        hipLaunchKernelGGL(k_shade, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, normals, pixels, shits, sdist, sslot, n, materials,
                            lights, nlights, slights, nslights, lit, samples, spawn, reinterpret_cast<float4*>(lvl), next_rays, next_pixels,
                            counters);
     return hipGetLastError();

@@ -41,8 +41,10 @@ hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0
 hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
                               unsigned long long nitems, uint32_t* lit, int anyhit, hipStream_t stream);
 
-// frame-ordered primary rays for the shading wavefront: n items = F.nblocks * 256; item_pixels[i] = y*W+x or -1
-hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, float* rays, int* item_pixels, hipStream_t stream);
+// primary frame for the shading wavefront: only the hits, appended to a compact list; count = one zeroed device word
+hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
+                                        int* pixels, uint32_t* count, hipStream_t stream);
+hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream);
 // shading wavefront (shade_kernels.hip); every level is a compact list of live paths
 // counters: 3 device words {shadow rays appended, mirror rays appended, hits}, zeroed by the caller before each level
 hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsigned long long n, const float* lights, unsigned nlights,

@@ -946,8 +946,8 @@ __device__ __forceinline__ void scan_leaves_quad(const SceneDev& S, const unsign
 
 // Spheres (bvh.cpp:878-879), result assembly and the accepted hit's interpolated normal
 // (ray_tracing.cpp:94-107), which depends only on the final (triangle, t).
-__device__ __forceinline__ void finish_ray(const SceneDev& S, const F3 o, const F3 d, float t, uint32_t hit_rec, CgrtHitDev* out,
-                                           float* out_normal) {
+__device__ __forceinline__ void resolve_hit(const SceneDev& S, const F3 o, const F3 d, float t, uint32_t hit_rec, const bool want_normal,
+                                            CgrtHitDev& h, F3& nn) {
     uint32_t prim = 0xffffffffu;
     int32_t mat = -1;
     bool hit = false;
@@ -967,19 +967,24 @@ __device__ __forceinline__ void finish_ray(const SceneDev& S, const F3 o, const 
             sphere_last = true;
         }
     }
-    CgrtHitDev h;
     h.t = t;
     h.prim_id = prim;
     h.material_id = mat;
     h.hit = hit ? 1u : 0u;
+    nn = sn;
+    if (want_normal && hit && !sphere_last) {
+        const TriRecord* T = S.tris + hit_rec;
+        const TriNormals* N = S.tri_normals + (hit_rec - S.tri_base);
+        nn = hit_normal(ld3(T->v0), ld3(T->v1), ld3(T->v2), ld3(T->n), ld3(N->n1), ld3(N->n2), ld3(N->n3), o, d, t);
+    }
+}
+__device__ __forceinline__ void finish_ray(const SceneDev& S, const F3 o, const F3 d, float t, uint32_t hit_rec, CgrtHitDev* out,
+                                           float* out_normal) {
+    CgrtHitDev h;
+    F3 nn;
+    resolve_hit(S, o, d, t, hit_rec, out_normal != nullptr, h, nn);
     *out = h;
-    if (out_normal && hit) {
-        F3 nn = sn;
-        if (!sphere_last) {
-            const TriRecord* T = S.tris + hit_rec;
-            const TriNormals* N = S.tri_normals + (hit_rec - S.tri_base);
-            nn = hit_normal(ld3(T->v0), ld3(T->v1), ld3(T->v2), ld3(T->n), ld3(N->n1), ld3(N->n2), ld3(N->n3), o, d, t);
-        }
+    if (out_normal && h.hit) {
         out_normal[0] = nn.x;
         out_normal[1] = nn.y;
         out_normal[2] = nn.z;
@@ -1278,6 +1283,59 @@ __global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 }
 
+// Primary frame for the shading wavefront (cgrt_render): the fused kernel's walk, but only the rays that HIT are written,
+// appended to a compact list {ray, hit, normal, pixel} (one atomic per wave, lanes ranked by ballot; waves finish
+// roughly in launch order, so the list keeps the frame's tile order).  Pixels that miss need no further work upstream
+// either (main.cpp:293: black).  count = one zeroed device word.
+__global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
+                                                float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    const int lane = threadIdx.x & 63;
+    int x = 0, y = 0;
+    const bool active = tile_pixel(F, lane, x, y);
+    LaneCounters cnt;
+    CgrtHitDev h;
+    h.hit = 0;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0), nn = f3(0, 0, 0);
+    if (active) {
+        primary_ray(C, F.W, F.H, x, y, o, d);
+        float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
+        uint32_t hit_rec = REF_NONE;
+        walk_tree<false>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
+        resolve_hit(S, o, d, t, hit_rec, true, h, nn);
+    }
+    const bool keep = active && h.hit != 0;
+    const unsigned long long m = __ballot(keep);
+    if (m == 0) return;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (keep) {
+        const unsigned long long idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        float* r = rays + 7 * idx;
+        r[0] = o.x;
+        r[1] = o.y;
+        r[2] = o.z;
+        r[3] = d.x;
+        r[4] = d.y;
+        r[5] = d.z;
+        r[6] = 3.402823466e+38f;
+        hits[idx] = h;
+        normals[3 * idx] = nn.x;
+        normals[3 * idx + 1] = nn.y;
+        normals[3 * idx + 2] = nn.z;
+        pixels[idx] = y * F.W + x;
+    }
+}
+// rgb of every pixel this rank owns := 0 (main.cpp:293; the hits are written over it afterwards)
+__global__ __launch_bounds__(CGRT_BLOCK) void k_clear_owned(FrameDev F, float* __restrict__ rgb) {
+    int x = 0, y = 0;
+    if (!tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y)) return;
+    float* p = rgb + 3ull * ((unsigned long long)y * F.W + x);
+    p[0] = p[1] = p[2] = 0.0f;
+}
+
 // dcount (optional): device word holding the number of rays actually present (<= n); the grid covers n.
 template <bool COUNT>
 __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
@@ -1370,37 +1428,6 @@ __global__ __launch_bounds__(CGRT_BLOCK) void k_generate_rays(CameraDev C, int W
     r[4] = d.y;
     r[5] = d.z;
     r[6] = 3.402823466e+38f;
-}
-
-// Primary rays in FRAME ORDER (item i = workgroup i / 256 of the primary kernel's decomposition, thread i % 256): the
-// shading wavefront keeps this order for every batch it sends through k_trace_batch, so its secondary rays inherit the
-// tile coherence and the XCD locality of the primary frame.  Items outside the frame get a ray that fails the root gate.
-__global__ __launch_bounds__(CGRT_BLOCK) void k_generate_rays_items(CameraDev C, FrameDev F, float* __restrict__ rays) {
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    int x = 0, y = 0;
-    float* r = rays + 7ull * ((unsigned long long)b * CGRT_BLOCK + tid);
-    if (tile_pixel_of(F, b, tid, x, y)) {
-        F3 o, d;
-        primary_ray(C, F.W, F.H, x, y, o, d);
-        r[0] = o.x;
-        r[1] = o.y;
-        r[2] = o.z;
-        r[3] = d.x;
-        r[4] = d.y;
-        r[5] = d.z;
-        r[6] = 3.402823466e+38f;
-    } else {
-        r[0] = r[1] = r[2] = 3.402823466e+38f;
-        r[3] = 1.0f;
-        r[4] = r[5] = 0.0f;
-        r[6] = 0.0f;
-    }
-}
-// item -> pixel index (y*W + x), or -1 for items outside the frame
-__global__ __launch_bounds__(CGRT_BLOCK) void k_item_pixels(FrameDev F, int* __restrict__ pix) {
-    int x = 0, y = 0;
-    const bool in = tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y);
-    pix[(unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x] = in ? y * F.W + x : -1;
 }
 
 // ---- element-wise primitives (src/ray_tracing.h:10-20) ----
@@ -1563,6 +1590,17 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
         hipLaunchKernelGGL(k_trace_batch<false>, dim3(blocks), dim3(CGRT_BLOCK), 0, stream, S, rays, n, hits, normals, counters, dcount);
     return hipGetLastError();
 }
+hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
+                                        int* pixels, uint32_t* count, hipStream_t stream) {
+    if (F.nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_primary_compact, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, rays, hits, normals, pixels, count);
+    return hipGetLastError();
+}
+hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream) {
+    if (F.nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_clear_owned, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, F, rgb);
+    return hipGetLastError();
+}
 hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
                               unsigned long long nitems, uint32_t* lit, int anyhit, hipStream_t stream) {
     const unsigned long long nthreads = nitems * Q.nlights * Q.samples;
@@ -1579,12 +1617,6 @@ hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0
     const unsigned long long n = (unsigned long long)(x1 - x0) * (unsigned long long)(y1 - y0);
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_generate_rays, dim3(grid_for(n, CGRT_BLOCK)), dim3(CGRT_BLOCK), 0, stream, C, W, H, x0, y0, x1, y1, rays);
-    return hipGetLastError();
-}
-hipError_t launch_generate_rays_items(const CameraDev& C, const FrameDev& F, float* rays, int* item_pixels, hipStream_t stream) {
-    if (F.nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_generate_rays_items, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, C, F, rays);
-    hipLaunchKernelGGL(k_item_pixels, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, F, item_pixels);
     return hipGetLastError();
 }
 hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,

@@ -10,6 +10,8 @@ cam = pkg.scenes.default_camera(W, H)
 for name, sd, depth in (("cornell", pkg.scenes.SceneData.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/scenes/cornell.npz")), 4),
                         ("cornell", pkg.scenes.SceneData.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/scenes/cornell.npz")), 2),
                         ("dragon800k", pkg.scenes.make_dragon(800_000), 2)):
+    if len(sys.argv) > 1 and sys.argv[1] != name:
+        continue
     sc = pkg.Scene(sd)
     best = None
     for _ in range(5):
