@@ -1284,8 +1284,8 @@ __global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
 }
 
 // Primary frame for the shading wavefront (cgrt_render): the fused kernel's walk, but only the rays that HIT are written,
-// appended to a compact list {ray, hit, normal, pixel} (one atomic per wave, lanes ranked by ballot; waves finish
-// roughly in launch order, so the list keeps the frame's tile order).  Pixels that miss need no further work upstream
+// appended to a compact list {ray, hit, normal, pixel} (one atomic per workgroup, lanes ranked by ballot; workgroups
+// finish roughly in launch order, so the list keeps the frame's tile order).  Pixels that miss need no further work upstream
 // either (main.cpp:293: black).  count = one zeroed device word.
 __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
                                                 float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count) {
@@ -1304,15 +1304,26 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
         walk_tree<false>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
         resolve_hit(S, o, d, t, hit_rec, true, h, nn);
     }
+    // one atomic per workgroup (same-address atomics serialise at the L2); the workgroup's LDS is only released when its
+    // last wave ends anyway, so waiting for it here costs no occupancy
     const bool keep = active && h.hit != 0;
     const unsigned long long m = __ballot(keep);
-    if (m == 0) return;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
+    __shared__ uint32_t s_cnt[CGRT_BLOCK / 64 + 1];
+    const unsigned w = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (unsigned k = 0; k < CGRT_BLOCK / 64; k++) {
+            const uint32_t c = s_cnt[k];
+            s_cnt[k] = tot;
+            tot += c;
+        }
+        s_cnt[CGRT_BLOCK / 64] = tot ? atomicAdd(count, tot) : 0u;
+    }
+    __syncthreads();
     if (keep) {
-        const unsigned long long idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long idx = s_cnt[CGRT_BLOCK / 64] + s_cnt[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         float* r = rays + 7 * idx;
         r[0] = o.x;
         r[1] = o.y;
