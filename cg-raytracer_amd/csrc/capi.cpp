@@ -574,16 +574,18 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     FrameDev F;
     if (!make_frame(W, H, 0, 0, W, H, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame or rank");
     const unsigned long long n = (unsigned long long)F.nblocks * 256ull;  // items: this rank's part of the frame in the primary kernel's order
-    // Level 0 = the n items of the frame; every deeper level is a compact list of mirror rays (at most one per entry of the
-    // level above, so n bounds every list); the shadow list of a level holds at most entries * L rays.
-    DevBuf rays, nrays, hits, normals, srays, shits, sdist, sslot, dlights, levels, drgb, dctr, ipix, pixa, pixb, dslights, dunits, dlit;
-    HIP_TRY(ipix.alloc(n * 4));
-    HIP_TRY(pixa.alloc(n * 4));
-    HIP_TRY(pixb.alloc(n * 4));
-    HIP_TRY(rays.alloc(n * 28));
-    HIP_TRY(nrays.alloc(n * 28));
-    HIP_TRY(hits.alloc(n * sizeof(CgrtHit)));
-    HIP_TRY(normals.alloc(n * 12));
+    // Every level is a compact list: level 0 = the primary rays that hit, level l + 1 = the mirror rays of level l (at most
+    // one per entry, so the number of primary hits bounds every list, and n bounds that); the shadow list of a level
+    // holds at most entries * L rays.  hits/normals/rays/pixels alternate between two sets (a level's mirror batch is
+    // traversed on a second stream while the level itself is still being shaded).
+    DevBuf rays[2], hits[2], normals[2], pix[2], ipix, srays, shits, sdist, sslot, dlights, levels, drgb, dctr, dslights, dunits, dlit;
+    HIP_TRY(ipix.alloc(n * 4));  // pixels of level 0, kept to the end
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(rays[k].alloc(n * 28));
+        HIP_TRY(hits[k].alloc(n * sizeof(CgrtHit)));
+        HIP_TRY(normals[k].alloc(n * 12));
+        HIP_TRY(pix[k].alloc(n * 4));
+    }
     HIP_TRY(srays.alloc(n * L * 28));
     HIP_TRY(shits.alloc(n * L * sizeof(CgrtHit)));
     HIP_TRY(sdist.alloc(n * L * 4));
@@ -591,7 +593,8 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     HIP_TRY(dlights.alloc((size_t)L * 24));
     HIP_TRY(levels.alloc((size_t)(max_level > 0 ? max_level : 1) * n * 32));
     HIP_TRY(drgb.alloc(npix * 12));
-    HIP_TRY(dctr.alloc(4 * sizeof(uint32_t)));
+    const size_t nctr = 4 * (size_t)(max_level + 1);
+    HIP_TRY(dctr.alloc(nctr * sizeof(uint32_t)));  // per level {shadow rays, mirror rays, hits, -}; the last block: [3] = primary hits
     if (L) HIP_TRY(hipMemcpy(dlights.p, lights, (size_t)L * 24, hipMemcpyHostToDevice));
     SoftDev Q{};
     if (SL) {
@@ -608,58 +611,79 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         Q.seed = soft->seed;
     }
     const CameraDev C = make_camera(*cam);
+    struct Aux {  // second stream + the events that order it against the default stream
+        hipStream_t s = nullptr;
+        hipEvent_t spawned = nullptr, traced = nullptr;
+        ~Aux() {
+            if (spawned) (void)hipEventDestroy(spawned);
+            if (traced) (void)hipEventDestroy(traced);
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } aux;
+    HIP_TRY(hipStreamCreateWithFlags(&aux.s, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&aux.spawned, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&aux.traced, hipEventDisableTiming));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, nullptr));
     int nlev = 0;
     std::vector<unsigned long long> level_count;  // entries per evaluated level
+    HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
     if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
         // level 0 = the primary rays that hit something, straight out of the fused primary kernel (pixels that miss are
         // black, main.cpp:293, and spawn nothing)
-        uint32_t* ctr = dctr.as<uint32_t>();  // {shadow rays appended, mirror rays appended, hits} of the level; [3] = primary hits
-        HIP_TRY(hipMemsetAsync(dctr.p, 0, 4 * sizeof(uint32_t), nullptr));
-        HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays.as<float>(), hits.as<CgrtHitDev>(), normals.as<float>(), ipix.as<int>(), ctr + 3,
-                                             nullptr));
+        uint32_t* const primary_hits = dctr.as<uint32_t>() + 4 * (size_t)max_level + 3;
+        HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(),
+                                             ipix.as<int>(), primary_hits, nullptr));
         st.primary_rays = owned_pixels(F);
         uint32_t nhit0 = 0;
-        HIP_TRY(hipMemcpy(&nhit0, ctr + 3, sizeof(nhit0), hipMemcpyDeviceToHost));
-        float* cur = rays.as<float>();
-        float* nxt = nrays.as<float>();
-        const int* cur_pix = ipix.as<int>();
-        int* nxt_pix = pixa.as<int>();
+        HIP_TRY(hipMemcpy(&nhit0, primary_hits, sizeof(nhit0), hipMemcpyDeviceToHost));
         unsigned long long cnt = nhit0;
         for (int level = 0; level < max_level && cnt > 0; level++) {
+            const int a = level & 1, b = a ^ 1;  // this level's buffer set, the next level's
             const int spawn = level + 1 < max_level;
-            HIP_TRY(hipMemsetAsync(dctr.p, 0, 4 * sizeof(uint32_t), nullptr));
-            if (L) {
-                HIP_TRY(launch_spawn_shadow(cur, hits.as<CgrtHitDev>(), cnt, dlights.as<float>(), L, srays.as<float>(), sdist.as<float>(),
-                                            sslot.as<int>(), ctr, nullptr));
-                // the grid covers the list's capacity, the kernel stops at the appended count
-                HIP_TRY(launch_trace_batch(s->dev, srays.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, nullptr, nullptr, ctr + 0));
+            const int* cur_pix = level == 0 ? ipix.as<int>() : pix[a].as<int>();
+            uint32_t* ctr = dctr.as<uint32_t>() + 4 * (size_t)level;
+            float* lvl = levels.as<float>() + (size_t)level * n * 8;
+            HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), cur_pix, cnt,
+                                 static_cast<const float*>(s->d_materials), dlights.as<float>(), L, spawn, srays.as<float>(), sdist.as<float>(),
+                                 sslot.as<int>(), lvl, rays[b].as<float>(), pix[b].as<int>(), ctr, nullptr));
+            // Level 0's mirror batch runs on the second stream, beside level 0's shadow batch (two batches of a few hundred
+            // thousand rays each; its grid covers the list's capacity -- one mirror ray per entry -- and the kernel stops at the
+            // appended count).  Deeper levels are small and often empty: their mirror batch is launched after the level's
+            // sync, exactly sized, or not at all.
+            const bool overlap = spawn && level == 0;
+            if (overlap) {
+                HIP_TRY(hipEventRecord(aux.spawned, nullptr));
+                HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
+                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cnt, hits[b].as<CgrtHitDev>(), normals[b].as<float>(), nullptr, aux.s,
+                                           ctr + 1));
+                HIP_TRY(hipEventRecord(aux.traced, aux.s));
             }
+            if (L)
+                HIP_TRY(launch_trace_batch(s->dev, srays.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, nullptr, nullptr, ctr + 0));
             if (SL) {
                 Q.level = (uint32_t)level;
                 HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));
-                HIP_TRY(launch_soft_shadow(s->dev, Q, cur, hits.as<CgrtHitDev>(), cur_pix, cnt, dlit.as<uint32_t>(), soft->closest_hit == 0, nullptr));
+                HIP_TRY(launch_soft_shadow(s->dev, Q, rays[a].as<float>(), hits[a].as<CgrtHitDev>(), cur_pix, cnt, dlit.as<uint32_t>(),
+                                           soft->closest_hit == 0, nullptr));
             }
-            HIP_TRY(launch_shade(cur, hits.as<CgrtHitDev>(), normals.as<float>(), cur_pix, shits.as<CgrtHitDev>(), sdist.as<float>(),
+            HIP_TRY(launch_shade(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), shits.as<CgrtHitDev>(), sdist.as<float>(),
                                  sslot.as<int>(), cnt, static_cast<const float*>(s->d_materials), dlights.as<float>(), L, dslights.as<float>(),
-                                 SL, dlit.as<uint32_t>(), Q.samples, spawn, levels.as<float>() + (size_t)level * n * 8, nxt, nxt_pix, ctr,
-                                 nullptr));
+                                 SL, dlit.as<uint32_t>(), Q.samples, lvl, nullptr));
+            if (overlap) HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));  // the next level (and the end of the frame) need the mirror hits
             nlev = level + 1;
             level_count.push_back(cnt);
             uint32_t h[4];
-            HIP_TRY(hipMemcpy(h, dctr.p, sizeof(h), hipMemcpyDeviceToHost));  // also the level's sync point
+            HIP_TRY(hipMemcpy(h, ctr, sizeof(h), hipMemcpyDeviceToHost));  // also the level's sync point
             st.shadow_rays += h[0];
             st.reflection_rays += h[1];
             st.soft_shadow_rays += (uint64_t)h[2] * SL * Q.samples;
             if (!spawn || h[1] == 0) break;
+            if (!overlap)
+                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), h[1], hits[b].as<CgrtHitDev>(), normals[b].as<float>(), nullptr, nullptr));
             cnt = h[1];
-            HIP_TRY(launch_trace_batch(s->dev, nxt, cnt, hits.as<CgrtHitDev>(), normals.as<float>(), nullptr, nullptr));
-            std::swap(cur, nxt);
-            cur_pix = nxt_pix;
-            nxt_pix = (nxt_pix == pixa.as<int>()) ? pixb.as<int>() : pixa.as<int>();
         }
     }
     if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data

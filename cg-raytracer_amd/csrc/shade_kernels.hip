@@ -44,17 +44,29 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counter, const bool w
 }
 #define CGRT_SHADE_BLOCK 1024
 
-// pointInShadow's ray construction (main.cpp:104-111) for every (hit entry, light), appended to the shadow list.
-__global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_spawn_shadow(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits, unsigned long long n,
-                               const float* __restrict__ lights, unsigned nlights, float* __restrict__ srays, float* __restrict__ sdist,
-                               int* __restrict__ sslot, uint32_t* __restrict__ counters) {
+// Everything a hit spawns, in one pass: pointInShadow's rays (main.cpp:104-111) for every light, appended to the level's
+// shadow list, and shade's mirror ray (:246-258), appended to the next level's list -- the mirror ray does not depend on
+// the shadow results, so its batch can be traversed on a second stream while this level's shadow batch runs.
+// lvl[2 i + 1] = {ks.xyz, child}; child = index of the mirror ray's entry on the next level, -1 when none was spawned.
+// counters[0] += shadow rays, counters[1] += mirror rays, counters[2] += hits.
+__global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_spawn(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits,
+                                                            const float* __restrict__ normals, const int* __restrict__ pixels,
+                                                            unsigned long long n, const float* __restrict__ materials,
+                                                            const float* __restrict__ lights, unsigned nlights, int spawn,
+                                                            float* __restrict__ srays, float* __restrict__ sdist, int* __restrict__ sslot,
+                                                            float4* __restrict__ lvl, float* __restrict__ next_rays,
+                                                            int* __restrict__ next_pixels, uint32_t* __restrict__ counters) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n;
     const bool hit = in && hits[i].hit != 0;
-    F3 pointOn = f3(0.f, 0.f, 0.f);
+    F3 pointOn = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 0.f), ks = f3(0.f, 0.f, 0.f);
     if (hit) {
         const float* r = rays + 7 * i;
-        pointOn = add(ldv(r), scale(ldv(r + 3), hits[i].t));
+        d = ldv(r + 3);
+        pointOn = add(ldv(r), scale(d, hits[i].t));
+        const int mid = hits[i].material_id;
+        // a hit that never wrote hitInfo.material (sphere only) reads an indeterminate Material upstream; default Material here
+        ks = mid >= 0 ? ldv(materials + 8 * mid + 3) : f3(0.f, 0.f, 0.f);
     }
     const float eps = 0.001f;
     __shared__ uint32_t s_tmp[CGRT_SHADE_BLOCK / 64 + 1];
@@ -75,31 +87,53 @@ __global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_spawn_shadow(const float* 
         s[6] = 3.402823466e+38f;
         sdist[idx] = length(toLight);
     }
+    // :246 tests ks.z only (comma operator); `spawn` = level + 1 < maxLevel (:267)
+    const bool wants_mirror = hit && !(ks.z <= 0.01f) && spawn;
+    const uint32_t child = block_append(counters + 1, wants_mirror, s_tmp);
+    if (wants_mirror) {
+        const F3 nrm = ldv(normals + 3 * i);
+        const float dn = dot(nrm, d);  // glm::reflect(I, N) = I - N * dot(N, I) * 2
+        const F3 refl = normalize(sub(d, scale(scale(nrm, dn), 2.0f)));
+        const F3 ro = add(pointOn, f3(eps * refl.x, eps * refl.y, eps * refl.z));
+        float* q = next_rays + 7ull * child;
+        q[0] = ro.x;
+        q[1] = ro.y;
+        q[2] = ro.z;
+        q[3] = refl.x;
+        q[4] = refl.y;
+        q[5] = refl.z;
+        q[6] = length(d);  // :254: t = |direction| of the parent ray
+        next_pixels[child] = pixels[i];
+    }
+    if (in) lvl[2 * i + 1] = make_float4(ks.x, ks.y, ks.z, __int_as_float(wants_mirror ? (int)child : -1));
+    // hits of the level: one atomic per workgroup
+    const uint32_t h = (uint32_t)__popcll(__ballot(hit));
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (unsigned k = 0; k < (blockDim.x >> 6); k++) tot += s_tmp[k];
+        if (tot) atomicAdd(counters + 2, tot);
+    }
 }
 
-// shading (main.cpp:160-235) + shade (:241-264) for one level.  lvl: per entry {colour.xyz, flags} {ks.xyz, child};
-// flags bit0 = hit; child = index of the mirror ray's entry on the next level, -1 when none was spawned.
-// counters[1] += mirror rays appended, counters[2] += hits.
-__global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_shade(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits, const float* __restrict__ normals,
-                        const int* __restrict__ pixels, const CgrtHitDev* __restrict__ shits, const float* __restrict__ sdist,
-                        const int* __restrict__ sslot, unsigned long long n, const float* __restrict__ materials,
-                        const float* __restrict__ lights, unsigned nlights, const float* __restrict__ slights, unsigned nslights,
-                        const uint32_t* __restrict__ lit, unsigned samples, int spawn, float4* __restrict__ lvl, float* __restrict__ next_rays,
-                        int* __restrict__ next_pixels, uint32_t* __restrict__ counters) {
+// shading (main.cpp:160-235) for one level: lvl[2 i] = {direct light.xyz, flags}, flags bit0 = hit.
+__global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_shade(const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits,
+                                                            const float* __restrict__ normals, const CgrtHitDev* __restrict__ shits,
+                                                            const float* __restrict__ sdist, const int* __restrict__ sslot,
+                                                            unsigned long long n, const float* __restrict__ materials,
+                                                            const float* __restrict__ lights, unsigned nlights,
+                                                            const float* __restrict__ slights, unsigned nslights,
+                                                            const uint32_t* __restrict__ lit, unsigned samples, float4* __restrict__ lvl) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < n;
-    const bool hit = in && hits[i].hit != 0;
-    float4 out0 = make_float4(0.f, 0.f, 0.f, 0.f), out1 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-    bool wants_mirror = false;
-    F3 mo = f3(0.f, 0.f, 0.f), md = f3(0.f, 0.f, 0.f);
-    float mt = 0.f;
-    if (hit) {
+    if (i >= n) return;
+    float4 out0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hits[i].hit) {
         const float* r = rays + 7 * i;
         const F3 o = ldv(r), d = ldv(r + 3);
         const F3 nrm = ldv(normals + 3 * i);
         const F3 pointOn = add(o, scale(d, hits[i].t));
         const int mid = hits[i].material_id;
-        // a hit that never wrote hitInfo.material (sphere only) reads an indeterminate Material upstream; default Material here
         const F3 kd = mid >= 0 ? ldv(materials + 8 * mid) : f3(0.f, 0.f, 0.f);
         const F3 ks = mid >= 0 ? ldv(materials + 8 * mid + 3) : f3(0.f, 0.f, 0.f);
         const float shininess = mid >= 0 ? materials[8 * mid + 6] : 1.0f;
@@ -142,41 +176,8 @@ __global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_shade(const float* __restr
             result = add(result, spec);
         }
         out0 = make_float4(result.x, result.y, result.z, __uint_as_float(1u));
-        out1 = make_float4(ks.x, ks.y, ks.z, __int_as_float(-1));
-        if (!(ks.z <= 0.01f) && spawn) {  // :246 tests ks.z only (comma operator); `spawn` = level + 1 < maxLevel (:267)
-            wants_mirror = true;
-            mo = add(pointOn, f3(eps * refl.x, eps * refl.y, eps * refl.z));
-            md = refl;
-            mt = length(d);  // :254: t = |direction| of the parent ray
-        }
     }
-    __shared__ uint32_t s_tmp[CGRT_SHADE_BLOCK / 64 + 1];
-    const uint32_t child = block_append(counters + 1, wants_mirror, s_tmp);
-    if (wants_mirror) {
-        float* q = next_rays + 7ull * child;
-        q[0] = mo.x;
-        q[1] = mo.y;
-        q[2] = mo.z;
-        q[3] = md.x;
-        q[4] = md.y;
-        q[5] = md.z;
-        q[6] = mt;
-        next_pixels[child] = pixels[i];
-        out1.w = __int_as_float((int)child);
-    }
-    if (in) {
-        lvl[2 * i] = out0;
-        lvl[2 * i + 1] = out1;
-    }
-    // hits of the level: one atomic per workgroup
-    const uint32_t h = (uint32_t)__popcll(__ballot(hit));
-    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = h;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (unsigned k = 0; k < (blockDim.x >> 6); k++) tot += s_tmp[k];
-        if (tot) atomicAdd(counters + 2, tot);
-    }
+    lvl[2 * i] = out0;
 }
 
 // colour = !hit ? 0 : (ks.z <= 0.01 ? direct : direct + childColour * ks)   (main.cpp:248, :262, :293); the child's
@@ -204,21 +205,20 @@ __global__ void k_write_rgb(const float4* __restrict__ lvl0, unsigned long long 
 
 static inline unsigned grid_for(unsigned long long n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
-hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsigned long long n, const float* lights, unsigned nlights,
-                               float* srays, float* sdist, int* sslot, uint32_t* counters, hipStream_t s) {
-    if (n && nlights)
-        hipLaunchKernelGGL(k_spawn_shadow, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, n, lights, nlights, srays,
-                           sdist, sslot, counters);
+hipError_t launch_spawn(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, unsigned long long n,
+                        const float* materials, const float* lights, unsigned nlights, int spawn, float* srays, float* sdist, int* sslot,
+                        float* lvl, float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s) {
+    if (n)
+        hipLaunchKernelGGL(k_spawn, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, normals, pixels, n, materials,
+                           lights, nlights, spawn, srays, sdist, sslot, reinterpret_cast<float4*>(lvl), next_rays, next_pixels, counters);
     return hipGetLastError();
 }
-hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, const CgrtHitDev* shits,
-                        const float* sdist, const int* sslot, unsigned long long n, const float* materials, const float* lights,
-                        unsigned nlights, const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, int spawn, float* lvl,
-                        float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s) {
+hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
+                        const int* sslot, unsigned long long n, const float* materials, const float* lights, unsigned nlights,
+                        const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s) {
     if (n)
-        hipLaunchKernelGGL(k_shade, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, normals, pixels, shits, sdist, sslot, n, materials,
-                           lights, nlights, slights, nslights, lit, samples, spawn, reinterpret_cast<float4*>(lvl), next_rays, next_pixels,
-                           counters);
+        hipLaunchKernelGGL(k_shade, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, normals, shits, sdist, sslot, n,
+                           materials, lights, nlights, slights, nslights, lit, samples, reinterpret_cast<float4*>(lvl));
     return hipGetLastError();
 }
 hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s) {

@@ -46,13 +46,15 @@ hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, c
                                         int* pixels, uint32_t* count, hipStream_t stream);
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream);
 // shading wavefront (shade_kernels.hip); every level is a compact list of live paths
-// counters: 3 device words {shadow rays appended, mirror rays appended, hits}, zeroed by the caller before each level
-hipError_t launch_spawn_shadow(const float* rays, const CgrtHitDev* hits, unsigned long long n, const float* lights, unsigned nlights,
-                               float* srays, float* sdist, int* sslot, uint32_t* counters, hipStream_t s);
-hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, const CgrtHitDev* shits,
-                        const float* sdist, const int* sslot, unsigned long long n, const float* materials, const float* lights,
-                        unsigned nlights, const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, int spawn, float* lvl,
-                        float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s);
+// counters: 3 device words {shadow rays appended, mirror rays appended, hits}, zeroed by the caller
+// k_spawn: shadow rays of every hit -> the level's shadow list; mirror rays -> the next level's list; lvl[2i+1] = {ks, child}
+hipError_t launch_spawn(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, unsigned long long n,
+                        const float* materials, const float* lights, unsigned nlights, int spawn, float* srays, float* sdist, int* sslot,
+                        float* lvl, float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s);
+// k_shade: lvl[2i] = {direct light, flags}
+hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
+                        const int* sslot, unsigned long long n, const float* materials, const float* lights, unsigned nlights,
+                        const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s);
 // colour of level `lvl` entries += colour of their child (level lvl + 1) * ks  (main.cpp:262)
 hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s);
 hipError_t launch_write_rgb(const float* lvl0, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
