@@ -90,6 +90,36 @@ def test_device_render_matches_oracle(pkg, orc, scene_data, name, W, H, level):
 
 
 @pytest.mark.gpu
+def test_device_render_edge_frames(pkg, orc, scene_data):
+    """Frames the compact wavefront has to survive: nothing hit at all (camera looks away -> no level is evaluated, the
+    frame is black), sphere-only hits (no material was ever written upstream: restated as the default Material), a mesh
+    scene with spheres in front, a frame smaller than one tile, and recursion deeper than any path goes."""
+    W, H = 96, 64
+    sd = scene_data("cornell")
+    away = np.asarray(pkg.scenes.default_camera(W, H), np.float32).copy()
+    away[0:3] = [50.0, 0.0, 0.0]  # the trackball looks at a point far from the box: nothing in view
+    s = pkg.Scene(sd)
+    rgb, st = s.render(away, W, H, max_level=3)
+    ref, nrays = orc.OracleScene(sd).render(away, W, H, sd.point_lights, max_level=3)
+    assert np.array_equal(rgb, ref) and st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"] == nrays
+    assert not ref.any() and st["levels"] == 0 and st["shadow_rays"] == 0
+    for name, w, h, level in (("spheres", 120, 80, 2), ("cornell", 5, 3, 2), ("cornell", 64, 40, 9)):
+        sdn = scene_data(name)
+        cam = pkg.scenes.default_camera(w, h) if name != "spheres" else np.asarray([0, 0, 6, 0, 0, 0, 8.0, np.radians(50.0), w / h], np.float32)
+        rgb, st = pkg.Scene(sdn).render(cam, w, h, max_level=level)
+        ref, nrays = orc.OracleScene(sdn).render(cam, w, h, sdn.point_lights, max_level=level)
+        assert np.abs(rgb.astype(np.float64) - ref).max() <= 1e-5, name
+        assert st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"] == nrays, name
+    sd2 = pkg.scenes.SceneData(pos_nrm=sd.pos_nrm, tri=sd.tri, tri_mesh=sd.tri_mesh, materials=sd.materials, point_lights=sd.point_lights,
+                               spheres=np.float32([[0.1, -0.2, 0.0, 0.25, -1], [-0.3, 0.2, 0.1, 0.2, -1]]))
+    cam = pkg.scenes.default_camera(W, H)
+    rgb, st = pkg.Scene(sd2).render(cam, W, H, max_level=3)
+    ref, nrays = orc.OracleScene(sd2).render(cam, W, H, sd2.point_lights, max_level=3)
+    assert np.abs(rgb.astype(np.float64) - ref).max() <= 1e-5
+    assert st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"] == nrays
+
+
+@pytest.mark.gpu
 def test_config3_device_render_1080p_depth4(pkg, orc, scene_data):
     """BASELINE.json config 3 on the device path: Cornell 1920x1080, recursion depth 4, RGB within 1e-5."""
     sd = scene_data("cornell")
