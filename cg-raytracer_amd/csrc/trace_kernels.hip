@@ -443,6 +443,9 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
 struct RayFast {
     F3 yh, yl;
     bool fd;
+    bool in_root;  // the origin is strictly inside the root box.  Every node box is the bound of a subset of the root's
+                   // vertices (exact min/max), hence inside the root box: an origin that is not strictly inside the root
+                   // box is strictly inside no node box, and startsInBox (bvh.cpp:647-661) is false without looking.
 };
 
 __device__ __forceinline__ float fdiv4(const float a, const float d, const float yh, const float yl) {
@@ -465,6 +468,7 @@ __device__ __forceinline__ RayFast make_rayfast(const SceneDev& S, const F3 o, c
     const bool ook = (o.x == 0.0f || in_fast_range(o.x, clo, chi)) && (o.y == 0.0f || in_fast_range(o.y, clo, chi)) &&
                      (o.z == 0.0f || in_fast_range(o.z, clo, chi));
     R.fd = dok && ook && (S.fast_boxes != 0);
+    R.in_root = starts_in_box(o, f3(S.root_box.lo[0], S.root_box.lo[1], S.root_box.lo[2]), f3(S.root_box.hi[0], S.root_box.hi[1], S.root_box.hi[2]));
     const float dx = R.fd ? d.x : 1.0f, dy = R.fd ? d.y : 1.0f, dz = R.fd ? d.z : 1.0f;
     R.yh = f3(1.0f / dx, 1.0f / dy, 1.0f / dz);  // true divisions: RN(1/d)
     R.yl = f3(__builtin_fmaf(-dx, R.yh.x, 1.0f) * R.yh.x, __builtin_fmaf(-dy, R.yh.y, 1.0f) * R.yh.y,
@@ -474,6 +478,7 @@ __device__ __forceinline__ RayFast make_rayfast(const SceneDev& S, const F3 o, c
 
 // ray_box + starts_in_box for one child box under RayFast::fd.  `inside` is bvh.cpp:647-661
 // (lo < o  <=>  lo - o < 0 exactly, denormals being preserved).
+template <bool INSIDE>
 __device__ __forceinline__ bool ray_box_fast(const F3 lo, const F3 hi, const F3 o, const F3 d, const RayFast& R, const float t,
                                              float& tbox, bool& inside) {
     const float ax0 = lo.x - o.x, ay0 = lo.y - o.y, az0 = lo.z - o.z;
@@ -483,7 +488,7 @@ __device__ __forceinline__ bool ray_box_fast(const F3 lo, const F3 hi, const F3 
     const float z0 = fdiv4(az0, d.z, R.yh.z, R.yl.z), z1 = fdiv4(az1, d.z, R.yh.z, R.yl.z);
     const float tIn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     const float tOut = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    inside = (fmaxf(fmaxf(ax0, ay0), az0) < 0.0f) && (fminf(fminf(ax1, ay1), az1) > 0.0f);
+    inside = INSIDE && (fmaxf(fmaxf(ax0, ay0), az0) < 0.0f) && (fminf(fminf(ax1, ay1), az1) > 0.0f);
     const float cur = (tIn < 0.0f) ? tOut : tIn;
     tbox = cur;
     return !((tIn > tOut) || (tOut < 0.0f)) && !(cur >= t);
@@ -536,35 +541,45 @@ __device__ __forceinline__ void topo_step(const SceneDev& S, const Walk& W, cons
     const uint4 m = *reinterpret_cast<const uint4*>(q + 3);
     const F3 llo = f3(a.x, a.y, a.z), lhi = f3(a.w, b.x, b.y);
     const F3 rlo = f3(b.z, b.w, c.x), rhi = f3(c.y, c.z, c.w);
-    float tL = -1.0f, tR = -1.0f, tb;
-    bool inL, inR;
-    if (W.R.fd) {
-        if (ray_box_fast(llo, lhi, o, d, W.R, W.t, tb, inL)) tL = tb;
-        if (ray_box_fast(rlo, rhi, o, d, W.R, W.t, tb, inR)) tR = tb;
-    } else {
-        if (ray_box(llo, lhi, o, d, W.t, tb)) tL = tb;
-        if (ray_box(rlo, rhi, o, d, W.t, tb)) tR = tb;
-        inL = starts_in_box(o, llo, lhi);
-        inR = starts_in_box(o, rlo, rhi);
-    }
     // Which child is entered first, which one is deferred (bvh.cpp:679-701 intersectDeeper, :611-635
     // intersectRayThatStartsOutsideBoxes), as selects:
     //   a child is visited iff the origin is strictly inside its box or its box test succeeded (not the -1 sentinel);
     //   left goes first when the origin is inside it (:685-692), or -- origin inside neither -- when only left was hit
     //   or both were and tL < tR (:626-633); the deferred child carries its own box parameter as tSecond, except when
     //   the origin is inside both boxes: then right is visited unconditionally (:685-688), i.e. tSecond = -inf.
-    const bool hitL = !(tL < 0), hitR = !(tR < 0);
-    const bool wantL = inL || hitL, wantR = inR || hitR;
-    const bool lfirst = wantL && (inL || !wantR || (!inR && tL < tR));
-    const uint32_t first = lfirst ? m.x : (wantR ? m.y : REF_NONE);
-    const uint32_t second = (wantL && wantR) ? (lfirst ? m.y : m.x) : REF_NONE;
-    const float tsec = (inL && inR) ? -__builtin_inff() : (lfirst ? tR : tL);
-    // branch-free push: the two slots above sp are always written and only kept when a child was deferred
-    // (at most MAX_LEVELS - 1 deferred children exist at any time, so the slots are inside the lane's slice)
-    stk[sp * CGRT_BLOCK] = second;
-    stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
-    sp += (second != REF_NONE) ? 2 : 0;
-    cur = first;
+    auto order_and_push = [&](const float tL, const float tR, const bool inL, const bool inR) __attribute__((always_inline)) {
+        const bool hitL = !(tL < 0), hitR = !(tR < 0);
+        const bool wantL = inL || hitL, wantR = inR || hitR;
+        const bool lfirst = wantL && (inL || !wantR || (!inR && tL < tR));
+        const uint32_t first = lfirst ? m.x : (wantR ? m.y : REF_NONE);
+        const uint32_t second = (wantL && wantR) ? (lfirst ? m.y : m.x) : REF_NONE;
+        const float tsec = (inL && inR) ? -__builtin_inff() : (lfirst ? tR : tL);
+        // branch-free push: the two slots above sp are always written and only kept when a child was deferred
+        // (at most MAX_LEVELS - 1 deferred children exist at any time, so the slots are inside the lane's slice)
+        stk[sp * CGRT_BLOCK] = second;
+        stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
+        sp += (second != REF_NONE) ? 2 : 0;
+        cur = first;
+    };
+    float tL = -1.0f, tR = -1.0f, tb;
+    bool inL, inR;
+    if (W.R.fd) {
+        if (__any(W.R.in_root)) {
+            if (ray_box_fast<true>(llo, lhi, o, d, W.R, W.t, tb, inL)) tL = tb;
+            if (ray_box_fast<true>(rlo, rhi, o, d, W.R, W.t, tb, inR)) tR = tb;
+            order_and_push(tL, tR, inL, inR);
+        } else {  // no origin of this wave is inside the root box (RayFast::in_root): no inside tests, simpler ordering
+            if (ray_box_fast<false>(llo, lhi, o, d, W.R, W.t, tb, inL)) tL = tb;
+            if (ray_box_fast<false>(rlo, rhi, o, d, W.R, W.t, tb, inR)) tR = tb;
+            order_and_push(tL, tR, false, false);
+        }
+    } else {
+        if (ray_box(llo, lhi, o, d, W.t, tb)) tL = tb;
+        if (ray_box(rlo, rhi, o, d, W.t, tb)) tR = tb;
+        inL = starts_in_box(o, llo, lhi);
+        inR = starts_in_box(o, rlo, rhi);
+        order_and_push(tL, tR, inL, inR);
+    }
 }
 
 // Pops deferred children until one is still wanted (bvh.cpp:582: a deferred child is skipped iff ray.t < tSecond).
