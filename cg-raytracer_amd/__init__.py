@@ -451,7 +451,7 @@ def host_lib() -> C.CDLL:
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
         H.cgrt_host_last_error.restype = C.c_char_p
         H.cgrt_host_render.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, vp, vp]
-        H.cgrt_host_render_soft.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32, u32, vp, i32, i32, i32, vp, vp]
+        H.cgrt_host_render_soft.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32, u32, vp, i32, i32, i32, vp, vp, i32]
         H.cgrt_host_load_obj.argtypes = [C.c_char_p, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp]
         H.cgrt_host_write_bmp.argtypes = [C.c_char_p, vp, i32, i32]
         H.cgrt_host_selftest.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, C.POINTER(i32)]
@@ -475,9 +475,10 @@ def host_render(sd: SceneData, cam, W: int, H: int, max_level: int = 2):
 
 
 def host_render_soft(sd: SceneData, cam, W: int, H: int, spherical, units=None, samples: int = 200, seed: int = 0, lights=None,
-                     max_level: int = 2):
+                     max_level: int = 2, on_device: bool = False):
     """renderRayTracing of the C++ host mirror for a scene with spherical lights (soft shadows, main.cpp:168-218).
-    units=None uses the mirror's own gaussian table (SoftShadowSampler::gaussian)."""
+    units=None uses the mirror's own gaussian table (SoftShadowSampler::gaussian); on_device=True runs the C++ mirror's
+    renderToBufferOnDevice (the whole driver on the GPU) instead of its host-driven wavefront."""
     Hl = host_lib()
     pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
     tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
@@ -488,7 +489,7 @@ def host_render_soft(sd: SceneData, cam, W: int, H: int, spherical, units=None, 
     st = np.zeros(6, np.float64)
     rc = Hl.cgrt_host_render_soft(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(lights), len(lights),
                                   _ptr(spherical), len(spherical), _ptr(units), len(units), samples, seed, _ptr(camv), W, H, max_level,
-                                  _ptr(rgb), _ptr(st))
+                                  _ptr(rgb), _ptr(st), int(on_device))
     if rc:
         raise RuntimeError("cgrt_host_render_soft: " + Hl.cgrt_host_last_error().decode())
     return rgb, dict(primary=int(st[0]), shadow=int(st[1]), reflection=int(st[2]), soft_shadow=int(st[3]), seconds_device=float(st[4]),

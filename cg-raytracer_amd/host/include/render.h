@@ -28,6 +28,13 @@ struct SoftShadowSampler {
 };
 
 // maxLevel = 2 reproduces main.cpp:267 (`level >= 2` -> black): primary + one mirror bounce.
+// The same frame with the whole driver ON THE DEVICE (cgrt_render_soft: primary rays, shadow and mirror batches and the
+// Phong terms never leave the GPU; one download of W*H*3 floats): the fast path for a caller that wants pixels.
+// RGB agrees with renderToBuffer to the 1e-5 parity bar (powf is the device's).
+RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
+                                   int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
+RenderStats renderRayTracingOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen,
+                                     int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
 // sampler: required when the scene has spherical lights (nullptr -> SoftShadowSampler::gaussian()).
 RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel = 2,
                              const SoftShadowSampler* sampler = nullptr);

@@ -73,10 +73,11 @@ int cgrt_host_render(const float* pos_nrm, uint32_t nverts, const uint32_t* tri,
 
 // + spherical lights (S x 7: position, radius, color) sampled from `units` (nunits x 3, 0 -> SoftShadowSampler::gaussian()).
 // stats: primary, shadow, reflection, soft-shadow ray counts, device seconds, total seconds.
+// on_device: 0 = the host-driven wavefront (renderToBuffer), 1 = the whole driver on the device (renderToBufferOnDevice).
 int cgrt_host_render_soft(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
                           const float* materials, uint32_t nmesh, const float* lights, uint32_t nlights, const float* spherical,
                           uint32_t nspherical, const float* units, uint32_t nunits, uint32_t samples, uint32_t seed, const float* cam, int W,
-                          int H, int maxLevel, float* rgb, double* stats) {
+                          int H, int maxLevel, float* rgb, double* stats, int on_device) {
     try {
         Scene sc = scene_from_arrays(pos_nrm, nverts, tri, tri_mesh, ntris, materials, nmesh, lights, nlights);
         for (uint32_t i = 0; i < nspherical; i++) {
@@ -94,7 +95,8 @@ int cgrt_host_render_soft(const float* pos_nrm, uint32_t nverts, const uint32_t*
         BoundingVolumeHierarchy bvh(&sc);
         Trackball camera(cam[7], cam[8], cam[6]);
         camera.setCamera(cgrt::vec3(cam[0], cam[1], cam[2]), cgrt::vec3(cam[3], cam[4], cam[5]), cam[6]);
-        RenderStats st = renderToBuffer(sc, camera, bvh, W, H, rgb, maxLevel, &sampler);
+        RenderStats st = on_device ? renderToBufferOnDevice(sc, camera, bvh, W, H, rgb, maxLevel, &sampler)
+                                   : renderToBuffer(sc, camera, bvh, W, H, rgb, maxLevel, &sampler);
         if (stats) {
             stats[0] = (double)st.primary;
             stats[1] = (double)st.shadow;

@@ -1,11 +1,15 @@
 // Wavefront restatement of the reference's render driver (src/main.cpp:61-310, :648-720).  See render.h.
 #include "render.h"
 
+#include "../../../include/cgrt.h"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <limits>
 #include <random>
+#include <stdexcept>
+#include <string>
 
 namespace {
 using cgrt::vec3;
@@ -244,6 +248,58 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
         rgb[3 * i + 2] = c.z;
     }
     st.seconds_total = std::chrono::duration<double>(Clock::now() - t_begin).count();
+    return st;
+}
+
+RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
+                                   int maxLevel, const SoftShadowSampler* sampler) {
+    const auto t_begin = Clock::now();
+    SoftShadowSampler fallback;
+    if (!scene.sphericalLight.empty() && (!sampler || sampler->units.empty() || sampler->samples == 0)) {
+        fallback = SoftShadowSampler::gaussian();
+        sampler = &fallback;
+    }
+    std::vector<float> lights, spherical, units;
+    for (const PointLight& l : scene.pointLights)
+        lights.insert(lights.end(), {l.position.x, l.position.y, l.position.z, l.color.x, l.color.y, l.color.z});
+    for (const SphericalLight& l : scene.sphericalLight)
+        spherical.insert(spherical.end(), {l.position.x, l.position.y, l.position.z, l.radius, l.color.x, l.color.y, l.color.z});
+    CgrtSoftShadows soft{};
+    if (!spherical.empty()) {
+        for (const vec3& u : sampler->units) units.insert(units.end(), {u.x, u.y, u.z});
+        soft.spherical = spherical.data();
+        soft.unit_vectors = units.data();
+        soft.nspherical = (uint32_t)scene.sphericalLight.size();
+        soft.samples = sampler->samples;
+        soft.nunits = (uint32_t)sampler->units.size();
+        soft.seed = sampler->seed;
+        soft.closest_hit = 0;
+    }
+    CgrtRenderStats cs{};
+    const CgrtCamera cam = camera.abi();
+    if (cgrt_render_soft(bvh.handle(), &cam, W, H, lights.data(), (uint32_t)scene.pointLights.size(), spherical.empty() ? nullptr : &soft, maxLevel, rgb,
+                         &cs) != 0)
+        throw std::runtime_error(std::string("cgrt_render_soft: ") + cgrt_last_error());
+    RenderStats st;
+    st.primary = cs.primary_rays;
+    st.shadow = cs.shadow_rays;
+    st.reflection = cs.reflection_rays;
+    st.softShadow = cs.soft_shadow_rays;
+    st.seconds_device = cs.device_ms * 1e-3;
+    st.seconds_total = std::chrono::duration<double>(Clock::now() - t_begin).count();
+    return st;
+}
+
+RenderStats renderRayTracingOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel,
+                                     const SoftShadowSampler* sampler) {
+    const int W = screen.width(), H = screen.height();
+    std::vector<float> rgb((size_t)W * H * 3);
+    RenderStats st = renderToBufferOnDevice(scene, camera, bvh, W, H, rgb.data(), maxLevel, sampler);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float* p = &rgb[3 * ((size_t)y * W + x)];
+            screen.setPixel(x, y, cgrt::vec3(p[0], p[1], p[2]));  // main.cpp:696
+        }
     return st;
 }
 

@@ -3,6 +3,7 @@
 // (main.cpp:791-797).
 //   render <data-dir> <triangle|cube|cornell|monkey|dragon|custom|file.obj> [W H [maxLevel [out.bmp]]]
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -38,7 +39,10 @@ int main(int argc, char** argv) {
         camera.setCamera(cgrt::vec3(0.0f), cgrt::vec3(20.0f * rad, 20.0f * rad, 0.0f), 3.0f);
         Screen screen{W, H};
         const auto start = std::chrono::high_resolution_clock::now();
-        const RenderStats st = renderRayTracing(scene, camera, bvh, screen, maxLevel);
+        // CGRT_RENDER_ON_DEVICE=1: the whole shading/recursion driver on the GPU instead of the host-driven wavefront
+        const char* od = std::getenv("CGRT_RENDER_ON_DEVICE");
+        const RenderStats st = (od && od[0] == '1') ? renderRayTracingOnDevice(scene, camera, bvh, screen, maxLevel)
+                                                     : renderRayTracing(scene, camera, bvh, screen, maxLevel);
         const auto end = std::chrono::high_resolution_clock::now();
         std::cout << "Time to render image: " << std::chrono::duration<float, std::milli>(end - start).count() << " milliseconds" << std::endl;
         std::cout << "BVH levels " << bvh.numLevels() << "; rays: " << st.primary << " primary, " << st.shadow << " shadow, " << st.reflection

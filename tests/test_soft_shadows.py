@@ -142,6 +142,10 @@ def test_host_mirror_soft_shadows_match_oracle(pkg, orc, scene_data):
     assert np.abs(rgb.astype(np.float64) - ref).max() <= 1e-5
     assert np.abs(rgb.astype(np.float64) - dev).max() <= 1e-5
     assert st["primary"] + st["shadow"] + st["reflection"] + st["soft_shadow"] == nrays
+    # the mirror's device-driven variant (renderToBufferOnDevice): the C++ surface over cgrt_render_soft
+    rgb_d, st_d = pkg.host_render_soft(sd, cam, W, H, sl, units, samples=24, seed=3, max_level=3, on_device=True)
+    assert np.array_equal(rgb_d, dev)
+    assert st_d["primary"] + st_d["shadow"] + st_d["reflection"] + st_d["soft_shadow"] == nrays
 
 
 @pytest.mark.gpu
