@@ -140,12 +140,43 @@ struct CgrtScene {
     unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, one per launch in flight
     unsigned launch_seq = 0;
     unsigned persistent_blocks = 1024;  // 4 workgroups per CU
+    // Device workspace of cgrt_render*: kept between frames (a frame of the same shape then allocates nothing; hipMalloc and
+    // hipFree of ~20 buffers cost more than the frame itself), grown on demand, released with the scene.
+    struct WorkSlot {
+        void* p = nullptr;
+        size_t cap = 0;
+    } work[24];
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
         for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, (void*)d_counters, (void*)d_queues})
             if (p) (void)hipFree(p);
+        for (WorkSlot& w : work)
+            if (w.p) (void)hipFree(w.p);
+    }
+};
+
+struct WsBuf {  // a slot of the scene's workspace, with DevBuf's interface
+    CgrtScene* sc;
+    int slot;
+    void* p = nullptr;
+    hipError_t alloc(size_t bytes) {
+        CgrtScene::WorkSlot& w = sc->work[slot];
+        if (w.cap < bytes || !w.p) {
+            if (w.p) (void)hipFree(w.p);
+            w.p = nullptr;
+            w.cap = 0;
+            const hipError_t e = hipMalloc(&w.p, bytes ? bytes : 1);
+            if (e != hipSuccess) return e;
+            w.cap = bytes ? bytes : 1;
+        }
+        p = w.p;
+        return hipSuccess;
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
     }
 };
 
@@ -578,7 +609,9 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     // one per entry, so the number of primary hits bounds every list, and n bounds that); the shadow list of a level
     // holds at most entries * L rays.  hits/normals/rays/pixels alternate between two sets (a level's mirror batch is
     // traversed on a second stream while the level itself is still being shaded).
-    DevBuf rays[2], hits[2], normals[2], pix[2], ipix, srays, shits, sdist, sslot, dlights, levels, drgb, dctr, dslights, dunits, dlit;
+    WsBuf rays[2] = {{s, 0}, {s, 1}}, hits[2] = {{s, 2}, {s, 3}}, normals[2] = {{s, 4}, {s, 5}}, pix[2] = {{s, 6}, {s, 7}}, ipix{s, 8},
+          srays{s, 9}, shits{s, 10}, sdist{s, 11}, sslot{s, 12}, dlights{s, 13}, levels{s, 14}, drgb{s, 15}, dctr{s, 16}, dslights{s, 17},
+          dunits{s, 18}, dlit{s, 19};
     HIP_TRY(ipix.alloc(n * 4));  // pixels of level 0, kept to the end
     for (int k = 0; k < 2; k++) {
         HIP_TRY(rays[k].alloc(n * 28));
