@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <utility>
 
 #include "cgrt_math.h"
@@ -279,9 +280,38 @@ struct SubBuilder {
     }
 };
 
+// The leaves are independent: contiguous ranges of them are built on worker threads into private node arrays, which are
+// then concatenated in leaf order -- the result is the array a single thread would have produced, node for node.
 void build_leaf_accelerators(BuiltBvh& out, int leaf_tris) {
-    SubBuilder sb{out.tris, out.tri_normals, out.subnodes, leaf_tris < 1 ? 1 : leaf_tris, {}, {}, {}, {}};
-    for (LeafRec& L : out.leaves) sb.run(L);
+    const int lt = leaf_tris < 1 ? 1 : leaf_tris;
+    const size_t nleaves = out.leaves.size();
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads < 1 || nleaves < 64) nthreads = 1;
+    std::vector<std::vector<SubNode>> part(nthreads);
+    auto work = [&](unsigned t) {
+        SubBuilder sb{out.tris, out.tri_normals, part[t], lt, {}, {}, {}, {}};  // leaves own disjoint record ranges
+        const size_t b = nleaves * t / nthreads, e = nleaves * (t + 1) / nthreads;
+        for (size_t i = b; i < e; i++) sb.run(out.leaves[i]);
+    };
+    if (nthreads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(work, t);
+        for (std::thread& th : pool) th.join();
+    }
+    for (unsigned t = 0; t < nthreads; t++) {
+        const uint32_t base = (uint32_t)out.subnodes.size();
+        for (SubNode N : part[t]) {
+            for (uint32_t* r : {&N.ref0, &N.ref1})
+                if (*r != REF_NONE && !(*r & REF_LEAF)) *r += base;  // node references were local to the part
+            out.subnodes.push_back(N);
+        }
+        const size_t b = nleaves * t / nthreads, e = nleaves * (t + 1) / nthreads;
+        for (size_t i = b; i < e; i++)
+            if (out.leaves[i].sub_root != REF_NONE) out.leaves[i].sub_root += base;
+    }
 }
 
 }  // namespace
@@ -336,16 +366,21 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         runs.push_back(std::move(r));
     }
 
-    std::vector<std::pair<float, uint32_t>> tmp;
-    std::vector<uint32_t> scratch;
-    for (size_t i = 0; i < out.nodes.size(); i++) {  // createTree, bvh.cpp:343-372
-        if (out.nodes[i].leaf) continue;
+    // createTree, bvh.cpp:343-372, level by level: the nodes of a level own disjoint ranges of `order`, so they are split on
+    // worker threads (every std::sort call is the sequential build's, on the same sequence -- the leaf order depends on
+    // it); their children are appended afterwards in node order, which is the numbering of the sequential build.
+    struct Split {
+        std::vector<Run> lr, rr;
+        uint32_t lcount = 0;
+        TopoNode left, right;
+    };
+    auto split_node = [&](size_t i, std::vector<std::pair<float, uint32_t>>& tmp, std::vector<uint32_t>& scratch, Split& R) {
         const TopoNode nd = out.nodes[i];
         std::vector<Run> my = std::move(runs[i]);
         const float ex = nd.box.hi[0] - nd.box.lo[0], ey = nd.box.hi[1] - nd.box.lo[1], ez = nd.box.hi[2] - nd.box.lo[2];
         const int axis = (ex > ey) ? ((ex > ez) ? 0 : 2) : ((ey > ez) ? 1 : 2);  // :289
 
-        std::vector<Run> lr, rr;
+        std::vector<Run>&lr = R.lr, &rr = R.rr;
         uint32_t lcount;
         if (my.size() > 1) {
             // bvh.cpp:168-179 / :88-110: order the MESHES by the centroid coordinate of the median
@@ -387,14 +422,41 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         const bool lvl = (nd.level + 1 == MAX_LEVELS - 1);  // :320
         const bool ll = lvl || (lr.size() == 1 && lr[0].count == 1);
         const bool rl = lvl || (rr.size() == 1 && rr[0].count == 1);
-        const int li = (int)out.nodes.size();
-        out.nodes[i].child[0] = li;
-        out.nodes[i].child[1] = li + 1;
-        out.nodes.push_back(TopoNode{ll, nd.level + 1, B.bounds(nd.first, lcount), {-1, -1}, nd.first, lcount});
-        out.nodes.push_back(
-            TopoNode{rl, nd.level + 1, B.bounds(nd.first + lcount, nd.count - lcount), {-1, -1}, nd.first + lcount, nd.count - lcount});
-        runs.push_back(std::move(lr));
-        runs.push_back(std::move(rr));
+        R.lcount = lcount;
+        R.left = TopoNode{ll, nd.level + 1, B.bounds(nd.first, lcount), {-1, -1}, nd.first, lcount};
+        R.right = TopoNode{rl, nd.level + 1, B.bounds(nd.first + lcount, nd.count - lcount), {-1, -1}, nd.first + lcount, nd.count - lcount};
+    };
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads < 1) nthreads = 1;
+    for (size_t lb = 0, le = out.nodes.size(); lb < le; lb = le, le = out.nodes.size()) {  // [lb, le) = the nodes of one level
+        std::vector<size_t> todo;
+        for (size_t i = lb; i < le; i++)
+            if (!out.nodes[i].leaf) todo.push_back(i);
+        std::vector<Split> res(todo.size());
+        const unsigned nt = (unsigned)std::min<size_t>(nthreads, todo.size());
+        auto work = [&](unsigned t) {
+            std::vector<std::pair<float, uint32_t>> tmp;
+            std::vector<uint32_t> scratch;
+            for (size_t k = t; k < todo.size(); k += nt) split_node(todo[k], tmp, scratch, res[k]);
+        };
+        if (nt <= 1) {
+            if (nt == 1) work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; t++) pool.emplace_back(work, t);
+            for (std::thread& th : pool) th.join();
+        }
+        for (size_t k = 0; k < todo.size(); k++) {
+            const size_t i = todo[k];
+            const int li = (int)out.nodes.size();
+            out.nodes[i].child[0] = li;
+            out.nodes[i].child[1] = li + 1;
+            out.nodes.push_back(res[k].left);
+            out.nodes.push_back(res[k].right);
+            runs.push_back(std::move(res[k].lr));
+            runs.push_back(std::move(res[k].rr));
+        }
     }
 
     int maxLevel = 0;
