@@ -56,9 +56,6 @@ namespace cgrt {
 #ifndef CGRT_SORT_FULL
 #define CGRT_SORT_FULL 1  // 0: only the nearest hit child of a 4-wide node is identified, the deferred ones are pushed unsorted
 #endif
-#ifndef CGRT_LEAF_LOOP
-#define CGRT_LEAF_LOOP 0
-#endif
 #ifndef CGRT_STAMP_SUB
 #define CGRT_STAMP_SUB 0  // diagnostic build: in-loop s_memtime stamps of the accelerator node step (load wait vs compute)
 #endif
@@ -328,21 +325,6 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
     } else if (SUB_WIDTH == 4) {
         int sp = sp0;
         uint32_t cur = LR.sub_root;
-#if CGRT_LEAF_LOOP == 1
-        // "if-if": every iteration a lane takes at most one node step, then (if it now stands on a run) one run test,
-        // then pops -- lanes never wait for others to finish a whole node phase.
-        while (cur != REF_NONE) {
-            if (!(cur & REF_LEAF)) sub_node_step<COUNT>(S, P, L.best_t, cur, sp, stk, cnt);
-            if (cur != REF_NONE && (cur & REF_LEAF)) {
-                test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, L, cnt);
-                cur = REF_NONE;
-            }
-            if (cur == REF_NONE && sp > sp0) {
-                sp -= 1;
-                cur = stk[sp * CGRT_BLOCK];
-            }
-        }
-#else
         for (;;) {
             // ---- node phase ----
             while (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, P, L.best_t, cur, sp, stk, cnt);
@@ -353,7 +335,6 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
             sp -= 1;
             cur = stk[sp * CGRT_BLOCK];
         }
-#endif
     } else {
         int sp = sp0;
         uint32_t cur = LR.sub_root;
