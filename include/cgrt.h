@@ -139,7 +139,7 @@ int cgrt_generate_rays(CgrtScene* scene, const CgrtCamera* cam, int W, int H, in
 /* The scene keeps the device workspace of these calls between frames (about 0.3 KB per pixel at 1920x1080 with one light
  * and max_level 2; it grows with the frame, the lights and the depth) and releases it in cgrt_scene_destroy. */
 typedef struct CgrtRenderStats {
-    uint64_t primary_rays, shadow_rays, reflection_rays; /* rays that exist upstream (null rays of dead paths not counted) */
+    uint64_t primary_rays, shadow_rays, reflection_rays; /* rays that exist upstream */
     int32_t levels;                                      /* recursion levels actually evaluated */
     float device_ms;                                     /* HIP-event time of all kernels of the frame */
     uint64_t soft_shadow_rays;                           /* samples towards spherical lights (cgrt_render_soft) */
