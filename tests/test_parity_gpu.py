@@ -476,6 +476,25 @@ def test_dragon_87k_full_frame_vs_oracle(pkg, orc):
     _assert_hits_equal(hits, normals, o.intersect(sc.generate_rays(cam, W, H)), "dragon87k")
 
 
+def test_config5_frame_on_one_gpu(pkg, orc):
+    """BASELINE.json config 5's frame (3840x2160, 800 K triangles) on ONE GPU: all 8.3 M pixels against the oracle
+    (flag, t bits, primitive id, material, normal bits), and its two-rank tiling merged into the same bytes."""
+    sd = pkg.scenes.make_dragon(800_000)
+    W, H = 3840, 2160
+    cam = pkg.scenes.default_camera(W, H)
+    sc = pkg.Scene(sd)
+    hits, normals = sc.trace_primary(cam, W, H, want_normals=True)
+    ref = orc.OracleScene(sd).intersect(sc.generate_rays(cam, W, H))
+    _assert_hits_equal(hits, normals, ref, "dragon800k 4K")
+    assert (hits["hit"] == 1).sum() > 500_000
+    merged = np.zeros_like(hits)
+    for r in range(2):
+        part, _ = sc.trace_primary(cam, W, H, rank=r, nranks=2)
+        own = pkg.tiling.owned_mask(W, H, r, 2).reshape(-1)
+        merged[own] = part[own]
+    assert merged.tobytes() == hits.tobytes()
+
+
 def test_dragon_800k_1080p_properties(pkg, orc):
     """Config 4 at full size.  Checked: (1) every 16th row against the oracle; (2) determinism;
     (3) tile partition invariance; (4) every reported hit re-verified by the element-wise triangle primitive:
