@@ -44,6 +44,9 @@ class Counters(C.Structure):
         ("leaf_visits", C.c_uint64),
         ("tri_tests", C.c_uint64),
         ("sub_visits", C.c_uint64),
+        ("cert_boxes", C.c_uint64),
+        ("fallback_rays", C.c_uint64),
+        ("tree_rays", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -98,7 +101,7 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/cgrt.h declares
 EXPORTS = [
-    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
+    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
     "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
@@ -129,6 +132,9 @@ def lib() -> C.CDLL:
     L.cgrt_num_subnodes.argtypes = [vp]
     L.cgrt_debug_check_layout.argtypes = [vp]
     L.cgrt_set_primary_mode.argtypes = [i32]
+    L.cgrt_set_fast_tree.argtypes = [i32]
+    L.cgrt_scene_set_walk.argtypes = [vp, i32]
+    L.cgrt_scene_walk.argtypes = [vp]
     L.cgrt_get_nodes.argtypes = [vp, vp, vp]
     L.cgrt_leaf_prims.argtypes = [vp, i32, vp, u32]
     L.cgrt_leaf_prims.restype = C.c_int64
@@ -183,6 +189,18 @@ def as_rays(origin, direction, t=None) -> np.ndarray:
     return r
 
 
+def _as_ray_array(rays) -> np.ndarray:
+    """RAY_DTYPE array from a RAY_DTYPE array or an (n, 7) float32 array {origin, direction, t} (viewed, never cast
+    element by element)."""
+    a = np.asarray(rays)
+    if a.dtype != RAY_DTYPE:
+        a = np.ascontiguousarray(a, np.float32)
+        if a.ndim != 2 or a.shape[1] != 7:
+            raise ValueError("rays must be a RAY_DTYPE array or an (n, 7) float32 array")
+        a = a.view(RAY_DTYPE).reshape(-1)
+    return np.ascontiguousarray(a)
+
+
 def record_sizes() -> dict:
     v = [C.c_uint32() for _ in range(4)]
     lib().cgrt_record_sizes(*[C.byref(x) for x in v])
@@ -197,6 +215,11 @@ def set_leaf_accel(enabled: bool = True, sub_leaf_tris: int = 0) -> None:
 def set_primary_mode(mode: int) -> None:
     """0 = one wave per 8x8 tile, 1 = persistent waves with lane refill (same results)."""
     _check(lib().cgrt_set_primary_mode(int(mode)))
+
+
+def set_fast_tree(mode: int) -> None:
+    """Process-wide build option: -1 = fast tree for scenes with fat leaves (default), 0 = never, 1 = whenever possible."""
+    _check(lib().cgrt_set_fast_tree(int(mode)))
 
 
 def device_count() -> int:
@@ -238,6 +261,14 @@ class Scene:
 
     __del__ = close
 
+    # ---- certified walk (same results as the exact walk) ----
+    def set_walk(self, certified: bool) -> None:
+        _check(lib().cgrt_scene_set_walk(self._h, 1 if certified else 0))
+
+    def walk(self) -> int:
+        """1 = certified walk (fast tree + certificate, exact walk as fallback), 0 = exact walk only."""
+        return int(lib().cgrt_scene_walk(self._h))
+
     # ---- introspection ----
     def num_levels(self) -> int:
         return int(lib().cgrt_num_levels(self._h))
@@ -269,7 +300,7 @@ class Scene:
     # ---- hot path ----
     def intersect(self, rays: np.ndarray, want_normals: bool = True):
         """Batched BoundingVolumeHierarchy::intersect. Returns (hits[HIT_DTYPE], normals or None)."""
-        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        rays = _as_ray_array(rays)
         hits = np.zeros(len(rays), HIT_DTYPE)
         normals = np.zeros((len(rays), 3), np.float32) if want_normals else None
         _check(lib().cgrt_intersect_batch(self._h, _ptr(rays), len(rays), _ptr(hits), _ptr(normals)))
@@ -370,7 +401,7 @@ class Scene:
         return out
 
     def count_batch(self, rays: np.ndarray) -> dict:
-        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        rays = _as_ray_array(rays)
         out = Counters()
         _check(lib().cgrt_count_batch(self._h, _ptr(rays), len(rays), C.byref(out)))
         return out.as_dict()

@@ -314,6 +314,218 @@ void build_leaf_accelerators(BuiltBvh& out, int leaf_tris) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast tree + certificates (DESIGN.md "Certified walk", walk_fast.h).
+//
+// The reference's own tree is a poor search structure (median splits, 12 levels, every step two exact box tests), but
+// its culling quirks are part of the result, so the exact walk must take every one of its steps.  The
+// certified walk searches a better structure first and then PROVES that the reference's walk ends in the same hit:
+//   * the fast tree: a 4-wide SAH tree over the reference LEAVES (their exact boxes), whose children are the leaves'
+//     in-leaf accelerators -- the closest accepted triangle over ALL leaves, found with conservative box tests only;
+//   * the certificate: for the leaf of that triangle, the boxes the reference tests on its way from the root to the
+//     leaf (paths).  If every one of them is entered at the final t (origin strictly inside, or the exact box test
+//     passes with parameter < t), the reference reaches the leaf whatever it met before -- ray.t never drops below the
+//     final t -- and accepts the same triangle; anything else (a failed box, an equal-t tie, an origin-on-plane
+//     acceptance) sends the ray through the exact walk.
+// Nothing here changes what the exact walk reads.
+struct TopBuilder {
+    const std::vector<Box6>& box;     // item boxes
+    const std::vector<uint32_t>& ref; // item references (accelerator roots or runs, builder-local indices)
+    std::vector<SubNode>& nodes;
+    std::vector<uint32_t> idx;
+    std::vector<float> cen[3];
+    std::vector<float> rarea;
+
+    static Box6 empty_box() {
+        Box6 b;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = std::numeric_limits<float>::infinity();
+            b.hi[a] = -std::numeric_limits<float>::infinity();
+        }
+        return b;
+    }
+    static void grow(Box6& b, const Box6& o) {
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = std::min(b.lo[a], o.lo[a]);
+            b.hi[a] = std::max(b.hi[a], o.hi[a]);
+        }
+    }
+    static float half_area(const Box6& b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+    Box6 range_box(uint32_t b, uint32_t e) const {
+        Box6 r = empty_box();
+        for (uint32_t i = b; i < e; i++) grow(r, box[idx[i]]);
+        return r;
+    }
+    static uint64_t capacity(int depth_left) {
+        uint64_t c = 1;
+        for (int i = 0; i < depth_left; i++) c *= 4u;
+        return c;
+    }
+    // SAH split of idx[b, e), full sweep on every axis; each side may hold at most `cap` items
+    uint32_t split(uint32_t b, uint32_t e, uint64_t cap) {
+        const uint32_t n = e - b;
+        const uint32_t kmin = (uint32_t)std::max<int64_t>(1, (int64_t)n - (int64_t)cap);
+        const uint32_t kmax = (uint32_t)std::min<uint64_t>(n - 1, cap);
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1;
+        uint32_t best_k = std::min(std::max(n / 2, kmin), kmax);
+        std::vector<uint32_t> ord[3];
+        rarea.resize(n);
+        for (int a = 0; a < 3; a++) {
+            ord[a].assign(idx.begin() + b, idx.begin() + e);
+            std::stable_sort(ord[a].begin(), ord[a].end(), [&](uint32_t p, uint32_t q) { return cen[a][p] < cen[a][q]; });
+            Box6 acc = empty_box();
+            for (uint32_t i = n; i-- > 1;) {
+                grow(acc, box[ord[a][i]]);
+                rarea[i] = half_area(acc);
+            }
+            acc = empty_box();
+            for (uint32_t k = 1; k < n; k++) {
+                grow(acc, box[ord[a][k - 1]]);
+                if (k < kmin || k > kmax) continue;
+                const float cost = half_area(acc) * (float)k + rarea[k] * (float)(n - k);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_k = k;
+                }
+            }
+        }
+        if (best_axis >= 0) std::copy(ord[best_axis].begin(), ord[best_axis].end(), idx.begin() + b);
+        return b + best_k;
+    }
+    uint32_t child_ref(uint32_t b, uint32_t e, int depth_left) { return (e - b == 1) ? ref[idx[b]] : build4(b, e, depth_left); }
+    uint32_t build4(uint32_t b, uint32_t e, int depth_left) {  // more than one item
+        const uint32_t me = (uint32_t)nodes.size();
+        nodes.push_back(SubNode());
+        nodes.push_back(SubNode());
+        const uint64_t cap1 = capacity(depth_left - 1);
+        const uint32_t m = split(b, e, 2 * cap1);
+        uint32_t cb[4], ce[4];
+        int nc = 0;
+        const uint32_t hb[2] = {b, m}, he[2] = {m, e};
+        for (int h = 0; h < 2; h++) {
+            if (he[h] - hb[h] > 1) {
+                const uint32_t q = split(hb[h], he[h], cap1);
+                cb[nc] = hb[h], ce[nc++] = q;
+                cb[nc] = q, ce[nc++] = he[h];
+            } else {
+                cb[nc] = hb[h], ce[nc++] = he[h];
+            }
+        }
+        Box6 cbox[4];
+        uint32_t cref[4];
+        for (int c = 0; c < 4; c++) {
+            if (c < nc) {
+                cbox[c] = range_box(cb[c], ce[c]);
+                cref[c] = child_ref(cb[c], ce[c], depth_left - 1);
+            } else {
+                cbox[c] = empty_box();
+                cref[c] = REF_NONE;
+            }
+        }
+        for (int r = 0; r < 2; r++) {
+            SubNode& N = nodes[me + r];
+            std::memcpy(N.box0, &cbox[2 * r], 24);
+            std::memcpy(N.box1, &cbox[2 * r + 1], 24);
+            N.ref0 = cref[2 * r];
+            N.ref1 = cref[2 * r + 1];
+            N.pad[0] = N.pad[1] = 0;
+        }
+        return me;
+    }
+};
+
+// Called before the references are made global: everything is still in builder-local indices (subnode index, record
+// index), which the globalisation loop of build_reference_bvh then shifts like every other accelerator reference.
+void build_fast_tree(BuiltBvh& out, bool force, int open) {
+    if (open < 0) open = 0;
+    if (open > SUB_MAX_DEPTH) open = SUB_MAX_DEPTH;
+    out.fast_root = REF_NONE;
+    out.paths.clear();
+    out.tri_leaf.clear();
+    const size_t nleaves = out.leaves.size();
+    if (SUB_WIDTH != 4 || nleaves == 0 || !out.geometry_finite) return;
+    if (!force && out.subnodes.empty()) return;  // no fat leaves: the reference tree already ends in single triangles
+    std::vector<Box6> box(nleaves);
+    std::vector<uint32_t> ref(nleaves);
+    for (size_t i = 0; i < out.nodes.size(); i++) {
+        const TopoNode& n = out.nodes[i];
+        if (!n.leaf) continue;
+        const uint32_t li = (uint32_t)out.node_to_ref_index[i];
+        const LeafRec& L = out.leaves[li];
+        box[li] = n.box;
+        if (L.sub_root != REF_NONE)
+            ref[li] = L.sub_root;
+        else if (L.count >= 1 && L.count <= SUB_RUN_MAX && (uint64_t)L.first + L.count <= SUB_MAX_RECORDS)
+            ref[li] = REF_LEAF | ((L.count - 1) << 26) | L.first;
+        else
+            return;  // a big leaf without accelerator (accelerator disabled or beyond its encoding): exact walk only
+    }
+    // paths: the boxes of the nodes between the root (exclusive) and each leaf (inclusive), top-down
+    std::vector<int> parent(out.nodes.size(), -1);
+    for (size_t i = 0; i < out.nodes.size(); i++)
+        if (!out.nodes[i].leaf) parent[out.nodes[i].child[0]] = parent[out.nodes[i].child[1]] = (int)i;
+    out.paths.assign(nleaves * PATH_BOXES * 6, 0.0f);
+    for (size_t i = 0; i < out.nodes.size(); i++) {
+        if (!out.nodes[i].leaf) continue;
+        const uint32_t li = (uint32_t)out.node_to_ref_index[i];
+        int chain[MAX_LEVELS], n = 0;
+        for (int k = (int)i; parent[k] >= 0; k = parent[k]) chain[n++] = k;  // the root (no parent) is not part of the path
+        out.leaves[li].path_len = (uint32_t)n;
+        for (int k = 0; k < n; k++) std::memcpy(&out.paths[((size_t)li * PATH_BOXES + k) * 6], &out.nodes[chain[n - 1 - k]].box, 24);
+    }
+    out.tri_leaf.resize(out.tris.size());
+    for (uint32_t li = 0; li < nleaves; li++)
+        for (uint32_t k = 0; k < out.leaves[li].count; k++) out.tri_leaf[out.leaves[li].first + k] = li;
+    // Items of the top tree: the leaves, or -- `open` levels further down -- the children of their accelerator nodes.  An
+    // opened leaf is no longer one subtree of the fast tree: the SAH then groups small clusters by position, whatever
+    // reference leaf they come from, which removes most of the overlap between the median-split leaves.
+    for (int lvl = 0; lvl < open; lvl++) {
+        std::vector<Box6> b2;
+        std::vector<uint32_t> r2;
+        for (size_t i = 0; i < ref.size(); i++) {
+            if (ref[i] & REF_LEAF) {
+                b2.push_back(box[i]);
+                r2.push_back(ref[i]);
+                continue;
+            }
+            for (int h = 0; h < 2; h++) {
+                const SubNode& N = out.subnodes[ref[i] + h];
+                const uint32_t cr[2] = {N.ref0, N.ref1};
+                const float* cb[2] = {N.box0, N.box1};
+                for (int c = 0; c < 2; c++) {
+                    if (cr[c] == REF_NONE) continue;
+                    Box6 bb;
+                    std::memcpy(&bb, cb[c], 24);
+                    b2.push_back(bb);
+                    r2.push_back(cr[c]);
+                }
+            }
+        }
+        box.swap(b2);
+        ref.swap(r2);
+    }
+    const uint32_t nitems = (uint32_t)ref.size();
+    if (nitems == 1) {
+        out.fast_root = ref[0];
+        return;
+    }
+    TopBuilder tb{box, ref, out.subnodes, {}, {}, {}};
+    tb.idx.resize(nitems);
+    for (int a = 0; a < 3; a++) tb.cen[a].resize(nitems);
+    for (uint32_t i = 0; i < nitems; i++) {
+        tb.idx[i] = i;
+        for (int a = 0; a < 3; a++) tb.cen[a][i] = 0.5f * box[i].lo[a] + 0.5f * box[i].hi[a];
+    }
+    out.fast_root = tb.build4(0, nitems, TOP_MAX_DEPTH + open);
+}
+
 }  // namespace
 
 bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh& out, std::string& err) {
@@ -486,7 +698,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
             L.first = w;
             L.count = n.count;
             L.sub_root = REF_NONE;
-            L.pad = 0;
+            L.path_len = 0;
             for (uint32_t k = 0; k < n.count; k++, w++) {
                 const uint32_t p = out.order[n.first + k];
                 const float* a = B.vpos(sc.tri[3 * (size_t)p]);
@@ -525,8 +737,10 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         for (int a = 0; a < 3; a++) {
             const float c = std::fabs(sc.pos_nrm[v + a]);
             if (c > out.scene_absmax) out.scene_absmax = c;  // NaN coordinates never raise it
+            if (!(c <= std::numeric_limits<float>::max())) out.geometry_finite = false;
         }
     if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
+    if (opt.fast_tree != 0) build_fast_tree(out, opt.fast_tree > 0, opt.fast_open);
     // one 64-byte record array on the device: [packets | subnodes | tris]; make sub/tri references global
     if (SUB_WIDTH == 4 && (out.packets.size() & 1u)) {
         NodePacket pad;  // keeps every 128-byte accelerator node inside one 128-byte line (the array is 256-byte aligned)
@@ -540,6 +754,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         out.subnodes.clear();
         for (LeafRec& L : out.leaves) L.sub_root = REF_NONE;
         out.tri_base = out.sub_base;
+        out.fast_root = REF_NONE;
     }
     for (LeafRec& L : out.leaves) {
         L.first += out.tri_base;
@@ -548,6 +763,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
     for (SubNode& N : out.subnodes)
         for (uint32_t* r : {&N.ref0, &N.ref1})
             if (*r != REF_NONE) *r += (*r & REF_LEAF) ? out.tri_base : out.sub_base;
+    if (out.fast_root != REF_NONE) out.fast_root += (out.fast_root & REF_LEAF) ? out.tri_base : out.sub_base;
     out.root_box = out.nodes[0].box;
     out.root_ref = ref_of(0);
     if (SUB_WIDTH == 4 && !out.subnodes.empty()) {

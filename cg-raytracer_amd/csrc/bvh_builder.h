@@ -40,6 +40,12 @@ struct BuiltBvh {
     std::vector<TriNormals> tri_normals;
     std::vector<SubNode> subnodes;       // in-leaf accelerators of all leaves (empty when disabled)
     float scene_absmax = 0;              // largest |vertex coordinate|
+    bool geometry_finite = true;         // no NaN / infinite vertex coordinate
+    // certified walk (walk_fast.h): 4-wide tree over the leaves (its nodes are appended to `subnodes`), per-leaf box paths,
+    // leaf of every record; fast_root == REF_NONE when the scene has none
+    uint32_t fast_root = REF_NONE;
+    std::vector<float> paths;            // nleaves x PATH_BOXES x 6
+    std::vector<uint32_t> tri_leaf;      // per TriRecord (leaf order)
     // The three kinds of 64-byte records live in ONE device array [packets | subnodes | tris]; after
     // globalize_refs() every reference to a subnode or triangle record is an index into that array.
     uint32_t sub_base = 0, tri_base = 0;
@@ -52,6 +58,8 @@ struct BuiltBvh {
 struct BuildOptions {
     bool leaf_accel = true;  // build the in-leaf accelerator (results are identical either way)
     int sub_leaf_tris = SUB_LEAF_TRIS;
+    int fast_open = 2;   // levels of the leaves' accelerators handed to the top tree's SAH as separate items (build_fast_tree)
+    int fast_tree = -1;  // certified walk's structures: -1 = when the reference tree has fat leaves (an accelerator exists), 0 = never, 1 = whenever possible
 };
 
 // Returns false and sets err on invalid input.

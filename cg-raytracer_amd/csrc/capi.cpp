@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <cstring>
 #include <new>
@@ -129,12 +130,20 @@ struct CgrtScene {
     int device = 0;
     BuiltBvh bvh;
     uint32_t ntris = 0;
-    SceneDev dev{};
+    SceneDev dev = [] {
+        SceneDev d{};
+        d.fast_root = REF_NONE;
+        d.root_ref = REF_NONE;
+        return d;
+    }();
     void* d_records = nullptr;  // [packets | subnodes | tris], 64 B each
     void* d_leaves = nullptr;
     void* d_tri_normals = nullptr;
     void* d_spheres = nullptr;
     void* d_materials = nullptr;  // nmesh x 8 floats, for the shading wavefront
+    void* d_tri_leaf = nullptr;   // certified walk: leaf of every record, per-leaf box paths (SceneDev::tri_leaf, paths)
+    void* d_paths = nullptr;
+    uint32_t fast_root = REF_NONE;  // the scene's fast tree (REF_NONE: none); dev.fast_root is this or REF_NONE by cgrt_scene_set_walk
     uint32_t nmesh = 0;
     unsigned long long* d_counters = nullptr;
     unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, one per launch in flight
@@ -150,7 +159,7 @@ struct CgrtScene {
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, (void*)d_counters, (void*)d_queues})
+        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_counters, (void*)d_queues})
             if (p) (void)hipFree(p);
         for (WorkSlot& w : work)
             if (w.p) (void)hipFree(w.p);
@@ -229,7 +238,9 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
         s->device = device;
         s->ntris = ntris;
         std::string err;
-        if (!build_reference_bvh(hs, g_build_options, s->bvh, err)) {
+        BuildOptions bo = g_build_options;
+        if (const char* e = getenv("CGRT_FAST_OPEN")) bo.fast_open = atoi(e);  // experiment knob
+        if (!build_reference_bvh(hs, bo, s->bvh, err)) {
             delete s;
             return fail(err.find("deeper") != std::string::npos ? CGRT_E_LIMIT : CGRT_E_ARG, err);
         }
@@ -261,7 +272,8 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
             return rc;
         }
         if ((rc = upload(s->bvh.leaves, &s->d_leaves, total)) || (rc = upload(s->bvh.tri_normals, &s->d_tri_normals, total)) ||
-            (rc = upload(s->bvh.spheres, &s->d_spheres, total))) {
+            (rc = upload(s->bvh.spheres, &s->d_spheres, total)) || (rc = upload(s->bvh.tri_leaf, &s->d_tri_leaf, total)) ||
+            (rc = upload(s->bvh.paths, &s->d_paths, total))) {
             delete s;
             return rc;
         }
@@ -290,6 +302,8 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
         D.leaves = static_cast<const LeafRec*>(s->d_leaves);
         D.tri_normals = static_cast<const TriNormals*>(s->d_tri_normals);
         D.spheres = static_cast<const SphereRecord*>(s->d_spheres);
+        D.tri_leaf = static_cast<const uint32_t*>(s->d_tri_leaf);
+        D.paths = static_cast<const float*>(s->d_paths);
         D.scene_eps = s->bvh.scene_absmax * 1.52587890625e-05f;  // 2^-16
         D.fast_boxes = 1;
         for (const TopoNode& n : s->bvh.nodes)
@@ -297,6 +311,9 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
                 const float c = std::fabs(k < 3 ? n.box.lo[k] : n.box.hi[k - 3]);
                 if (!(c == 0.0f || (c >= 9.094947017729282e-13f && c <= 1099511627776.0f))) D.fast_boxes = 0;
             }
+        // the certificates use the exact fast division, so they need the box envelope too (RayFast::fd is false without it)
+        s->fast_root = D.fast_boxes ? s->bvh.fast_root : REF_NONE;
+        D.fast_root = s->fast_root;
         D.root_box = s->bvh.root_box;
         D.root_ref = s->bvh.root_ref;
         D.ntris = ntris;
@@ -323,6 +340,18 @@ int cgrt_set_primary_mode(int mode) {
     g_primary_mode = mode;
     return CGRT_OK;
 }
+int cgrt_set_fast_tree(int mode) {
+    if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (scenes with fat leaves), 0 (never) or 1 (whenever possible)");
+    g_build_options.fast_tree = mode;
+    return CGRT_OK;
+}
+int cgrt_scene_set_walk(CgrtScene* s, int certified) {
+    if (!s) return fail(CGRT_E_ARG, "scene is NULL");
+    if (certified && s->fast_root == REF_NONE) return fail(CGRT_E_ARG, "the scene has no fast tree");
+    s->dev.fast_root = certified ? s->fast_root : REF_NONE;
+    return CGRT_OK;
+}
+int cgrt_scene_walk(const CgrtScene* s) { return s ? (s->dev.fast_root != REF_NONE ? 1 : 0) : fail(CGRT_E_ARG, "scene is NULL"); }
 int cgrt_num_subnodes(const CgrtScene* s) { return s ? (int)s->bvh.subnodes.size() : fail(CGRT_E_ARG, "scene is NULL"); }
 
 int cgrt_num_levels(const CgrtScene* s) { return s ? s->bvh.levels : fail(CGRT_E_ARG, "scene is NULL"); }
@@ -419,6 +448,44 @@ int cgrt_debug_check_layout(CgrtScene* s) {
     }
     for (uint32_t t = 0; t < ntri; t++)
         if (tri_seen[t] != 1) return fail(CGRT_E_ARG, "a triangle record is reachable " + std::to_string(tri_seen[t]) + " times");
+    if (B.fast_root != REF_NONE) {
+        // the fast tree: every reference leaf hangs under it exactly once (as its accelerator root, or as the run of its
+        // records), at most TOP_MAX_DEPTH levels deep; paths and tri_leaf describe the reference tree
+        if (B.tri_leaf.size() != ntri || B.paths.size() != (size_t)nleaf * PATH_BOXES * 6) return fail(CGRT_E_ARG, "fast tree tables have the wrong size");
+        std::vector<uint32_t> seen2(ntri, 0);
+        std::vector<std::pair<uint32_t, int>> todo{{B.fast_root, 0}};
+        while (!todo.empty()) {
+            const uint32_t r = todo.back().first;
+            const int depth = todo.back().second;
+            todo.pop_back();
+            if (r == REF_NONE) continue;
+            if (r & REF_LEAF) {
+                const uint32_t first = r & REF_INDEX26, cnt = ((r >> 26) & 31u) + 1u;
+                if (first < B.tri_base || (uint64_t)first - B.tri_base + cnt > ntri) return fail(CGRT_E_ARG, "fast tree: run out of range");
+                for (uint32_t k = 0; k < cnt; k++) seen2[first - B.tri_base + k]++;
+                continue;
+            }
+            if (r < B.sub_base || r >= B.tri_base || ((r - B.sub_base) & 1u)) return fail(CGRT_E_ARG, "fast tree: node reference out of range");
+            if (depth >= (int)(FAST_STACK_ENTRIES / (SUB_WIDTH - 1))) return fail(CGRT_E_ARG, "fast tree deeper than its stack allows");
+            for (uint32_t h = 0; h < 2; h++) {
+                const SubNode& N = B.subnodes[r - B.sub_base + h];
+                todo.push_back({N.ref0, depth + 1});
+                todo.push_back({N.ref1, depth + 1});
+            }
+        }
+        for (uint32_t t = 0; t < ntri; t++)
+            if (seen2[t] != 1) return fail(CGRT_E_ARG, "fast tree: a triangle record is reachable " + std::to_string(seen2[t]) + " times");
+        for (size_t i = 0; i < B.nodes.size(); i++) {
+            if (!B.nodes[i].leaf) continue;
+            const uint32_t li = (uint32_t)B.node_to_ref_index[i];
+            const LeafRec& L = B.leaves[li];
+            if ((int)L.path_len != B.nodes[i].level) return fail(CGRT_E_ARG, "path length != leaf level");
+            if (L.path_len && std::memcmp(&B.paths[((size_t)li * PATH_BOXES + L.path_len - 1) * 6], &B.nodes[i].box, 24) != 0)
+                return fail(CGRT_E_ARG, "a path does not end in its leaf's box");
+            for (uint32_t k = 0; k < L.count; k++)
+                if (B.tri_leaf[L.first - B.tri_base + k] != li) return fail(CGRT_E_ARG, "tri_leaf does not match the leaf table");
+        }
+    }
     return CGRT_OK;
 }
 
@@ -522,7 +589,7 @@ int cgrt_generate_rays(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
 }
 
 static int read_counters(CgrtScene* s, CgrtCounters* out) {
-    unsigned long long h[5];
+    unsigned long long h[8];
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out->rays = h[0];
@@ -530,6 +597,9 @@ static int read_counters(CgrtScene* s, CgrtCounters* out) {
     out->leaf_visits = h[2];
     out->tri_tests = h[3];
     out->sub_visits = h[4];
+    out->cert_boxes = h[5];
+    out->fallback_rays = h[6];
+    out->tree_rays = h[7];
     return CGRT_OK;
 }
 

@@ -33,7 +33,7 @@ struct LeafRec {
     uint32_t first;  // first TriRecord
     uint32_t count;
     uint32_t sub_root;  // index of the leaf's first SubNode, REF_NONE when the leaf is scanned linearly
-    uint32_t pad;
+    uint32_t path_len;  // boxes on the way from the root's child down to this leaf (its own box last): SceneDev::paths
 };
 static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
 
@@ -61,6 +61,14 @@ static const int SUB_WIDTH = CGRT_SUB_WIDTH;
 static const int SUB_MAX_DEPTH = CGRT_SUB_MAX_DEPTH;               // levels of the accelerator under one reference leaf
 static const int SUB_STACK_ENTRIES = (SUB_WIDTH - 1) * SUB_MAX_DEPTH;  // a step defers at most WIDTH-1 children
 static const int SUB_LEAF_TRIS = 2;    // target triangles per run (1..4 measure within 3 % of each other on the dragon frame)
+// The "fast tree" (walk_fast.h, DESIGN.md "Certified walk"): a 4-wide tree over the reference LEAVES whose children are the leaves'
+// in-leaf accelerators (or runs of records for small leaves), made of the same 128-byte nodes.  TOP_MAX_DEPTH levels
+// hold the <= 2^(MAX_LEVELS-1) leaves of a reference tree; its deferred children share the per-lane LDS stack.
+static const int TOP_MAX_DEPTH = 6;
+static_assert((1 << (2 * TOP_MAX_DEPTH)) >= (1 << (MAX_LEVELS - 1)), "the top tree must hold every reference leaf");
+static const int FAST_STACK_ENTRIES = (SUB_WIDTH - 1) * (TOP_MAX_DEPTH + SUB_MAX_DEPTH);
+static_assert(SUB_WIDTH != 4 || FAST_STACK_ENTRIES <= 2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES, "the fast walk's stack must fit the exact walk's LDS slice");
+static const int PATH_BOXES = MAX_LEVELS - 1;  // boxes per leaf in SceneDev::paths (6 floats each)
 
 // One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent
 // trianglePlane (ray_tracing.cpp:74-82) evaluated once on the host with the reference's arithmetic.
@@ -103,6 +111,10 @@ struct SceneDev {
     const LeafRec* leaves;
     const TriNormals* tri_normals;  // indexed by (record index - tri_base)
     const SphereRecord* spheres;
+    // certified walk (walk_fast.h); fast_root == REF_NONE: the scene has no fast tree and every ray takes the exact walk
+    const uint32_t* tri_leaf;  // leaf-table index of every TriRecord, indexed by (record index - tri_base)
+    const float* paths;        // per leaf PATH_BOXES x {lower.xyz, upper.xyz}: the boxes the reference tests on the way to the leaf
+    uint32_t fast_root;
     Box6 root_box;
     float scene_eps;    // 2^-16 * largest |coordinate| of the scene: conservative slack of the in-leaf boxes
     uint32_t fast_boxes;  // every reference box coordinate is 0 or in [2^-40, 2^40]: trace_kernels.hip RayFast

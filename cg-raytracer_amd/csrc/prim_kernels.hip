@@ -1,0 +1,163 @@
+// prim_kernels.hip -- the free functions of src/ray_tracing.h:10-20, element-wise on the device (one call per lane), for
+// kernel-level parity tests of the arithmetic in cgrt_math.h; plus two diagnostic kernels (FETCH_SIZE calibration, the
+// exact fast division against IEEE a / d).  HBM-bound streaming, 100-150 B per element; not part of the traversal.
+#include <hip/hip_runtime.h>
+
+#include "walk_exact.h"
+
+namespace cgrt {
+
+// ---- element-wise primitives (src/ray_tracing.h:10-20) ----
+__global__ void k_ray_triangle(const float* __restrict__ tri, const float* __restrict__ rays, unsigned long long n,
+                               float* __restrict__ t_out, uint8_t* __restrict__ hit, float* __restrict__ normals) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = tri + 18 * i;
+    const float* r = rays + 7 * i;
+    const F3 v0 = ld3(q), v1 = ld3(q + 3), v2 = ld3(q + 6);
+    const F3 o = ld3(r), d = ld3(r + 3);
+    float t = r[6];
+    F3 pn;
+    float D;
+    triangle_plane(v0, v1, v2, pn, D);  // the reference rebuilds the plane per call (ray_tracing.cpp:88)
+    const bool h = ray_triangle_geom(v0, v1, v2, pn, D, o, d, t);
+    t_out[i] = t;
+    hit[i] = h;
+    if (h && normals) {
+        const F3 nn = hit_normal(v0, v1, v2, pn, ld3(q + 9), ld3(q + 12), ld3(q + 15), o, d, t);
+        normals[3 * i] = nn.x;
+        normals[3 * i + 1] = nn.y;
+        normals[3 * i + 2] = nn.z;
+    }
+}
+__global__ void k_ray_plane(const float* __restrict__ plane, const float* __restrict__ rays, unsigned long long n,
+                            float* __restrict__ t_out, uint8_t* __restrict__ hit) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 7 * i;
+    float t = r[6];
+    hit[i] = ray_plane(plane[4 * i], ld3(plane + 4 * i + 1), ld3(r), ld3(r + 3), t);
+    t_out[i] = t;
+}
+__global__ void k_ray_box(const float* __restrict__ box, const float* __restrict__ rays, unsigned long long n,
+                          float* __restrict__ t_out, uint8_t* __restrict__ hit, uint8_t* __restrict__ inside) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 7 * i;
+    const F3 lo = ld3(box + 6 * i), hi = ld3(box + 6 * i + 3), o = ld3(r), d = ld3(r + 3);
+    float t = r[6], tb;
+    const bool h = ray_box(lo, hi, o, d, t, tb);
+    t_out[i] = h ? tb : t;  // the reference writes ray.t = box parameter on success (ray_tracing.cpp:198)
+    hit[i] = h;
+    if (inside) inside[i] = starts_in_box(o, lo, hi);
+}
+__global__ void k_ray_sphere(const float* __restrict__ sph, const float* __restrict__ rays, unsigned long long n,
+                             float* __restrict__ t_out, uint8_t* __restrict__ hit, float* __restrict__ normals) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 7 * i;
+    float t = r[6];
+    F3 nn = f3(0, 0, 0);
+    const bool h = ray_sphere(ld3(sph + 4 * i), sph[4 * i + 3], ld3(r), ld3(r + 3), t, nn);
+    t_out[i] = t;
+    hit[i] = h;
+    if (h && normals) {
+        normals[3 * i] = nn.x;
+        normals[3 * i + 1] = nn.y;
+        normals[3 * i + 2] = nn.z;
+    }
+}
+__global__ void k_triangle_plane(const float* __restrict__ tri, unsigned long long n, float* __restrict__ plane) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 pn;
+    float D;
+    triangle_plane(ld3(tri + 9 * i), ld3(tri + 9 * i + 3), ld3(tri + 9 * i + 6), pn, D);
+    plane[4 * i] = D;
+    plane[4 * i + 1] = pn.x;
+    plane[4 * i + 2] = pn.y;
+    plane[4 * i + 3] = pn.z;
+}
+__global__ void k_point_in_triangle(const float* __restrict__ in, unsigned long long n, uint8_t* __restrict__ out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = in + 15 * i;
+    out[i] = point_in_triangle(ld3(q), ld3(q + 3), ld3(q + 6), ld3(q + 9), ld3(q + 12));
+}
+
+// calibration kernel for the FETCH_SIZE counter: every lane reads ONE 64-byte record (4 x dwordx4, the access shape of
+// the traversal kernels) at a pseudo-random, never repeated position of a table far larger than the Infinity Cache.
+__global__ void k_gather_calib(const float4* __restrict__ table, unsigned long long nrecords, unsigned long long mult,
+                               unsigned long long add, float* __restrict__ sink) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrecords) return;
+    const unsigned long long j = (i * mult + add) % nrecords;  // mult coprime with nrecords: a permutation
+    const float4* q = table + 4 * j;
+    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    const float v = a.x + b.y + c.z + e.w;
+    if (v == 123456.0f) sink[0] = v;  // keeps the loads alive
+}
+
+// diagnostic / test kernel: fdiv4 against IEEE a / d, bit for bit (zeros compare equal regardless of sign)
+__global__ void k_fastdiv_check(const float* __restrict__ a, const float* __restrict__ d, unsigned long long n,
+                                unsigned long long* __restrict__ mismatches, float* __restrict__ first_bad) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dd = d[i], aa = a[i];
+    const float yh = 1.0f / dd;
+    const float yl = __builtin_fmaf(-dd, yh, 1.0f) * yh;
+    const float q = fdiv4(aa, dd, yh, yl), ref = aa / dd;
+    const bool same = (__float_as_uint(q) == __float_as_uint(ref)) || (q == 0.0f && ref == 0.0f);
+    if (!same) {
+        if (atomicAdd(mismatches, 1ull) == 0ull) {
+            first_bad[0] = aa;
+            first_bad[1] = dd;
+            first_bad[2] = q;
+            first_bad[3] = ref;
+        }
+    }
+}
+
+static inline unsigned grid_for(unsigned long long n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
+                               hipStream_t s) {
+    if (nrecords)
+        hipLaunchKernelGGL(k_gather_calib, dim3(grid_for(nrecords, 256)), dim3(256), 0, s, static_cast<const float4*>(table), nrecords, mult,
+                           add, sink);
+    return hipGetLastError();
+}
+hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,
+                                hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fastdiv_check, dim3(grid_for(n, 256)), dim3(256), 0, s, a, d, n, mismatches, first_bad);
+    return hipGetLastError();
+}
+hipError_t launch_ray_triangle(const float* tri, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, float* normals,
+                               hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_ray_triangle, dim3(grid_for(n, 256)), dim3(256), 0, s, tri, rays, n, t_out, hit, normals);
+    return hipGetLastError();
+}
+hipError_t launch_ray_plane(const float* plane, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_ray_plane, dim3(grid_for(n, 256)), dim3(256), 0, s, plane, rays, n, t_out, hit);
+    return hipGetLastError();
+}
+hipError_t launch_ray_box(const float* box, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, uint8_t* inside,
+                          hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_ray_box, dim3(grid_for(n, 256)), dim3(256), 0, s, box, rays, n, t_out, hit, inside);
+    return hipGetLastError();
+}
+hipError_t launch_ray_sphere(const float* sph, const float* rays, unsigned long long n, float* t_out, uint8_t* hit, float* normals,
+                             hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_ray_sphere, dim3(grid_for(n, 256)), dim3(256), 0, s, sph, rays, n, t_out, hit, normals);
+    return hipGetLastError();
+}
+hipError_t launch_triangle_plane(const float* tri, unsigned long long n, float* plane, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_triangle_plane, dim3(grid_for(n, 256)), dim3(256), 0, s, tri, n, plane);
+    return hipGetLastError();
+}
+hipError_t launch_point_in_triangle(const float* in, unsigned long long n, uint8_t* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_point_in_triangle, dim3(grid_for(n, 256)), dim3(256), 0, s, in, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace cgrt

@@ -66,7 +66,10 @@ typedef struct CgrtCounters {
     uint64_t inner_visits; /* reference inner nodes visited (intersectNonLeaf calls, bvh.cpp:715) */
     uint64_t leaf_visits;  /* reference leaves visited (intersectLeaf calls, bvh.cpp:535) */
     uint64_t tri_tests;    /* triangle records tested on the device */
-    uint64_t sub_visits;   /* in-leaf accelerator nodes visited (0 when leaves are scanned linearly) */
+    uint64_t sub_visits;   /* 4-wide nodes visited: in-leaf accelerators (exact walk) and the fast tree (certified walk) */
+    uint64_t cert_boxes;   /* certified walk: path boxes tested by certificates (24 B each) */
+    uint64_t fallback_rays; /* certified walk: rays that got no certificate and took the exact walk afterwards */
+    uint64_t tree_rays;    /* rays that passed the root gate (intersectDataStructure, bvh.cpp:835-836) and walked the tree */
 } CgrtCounters;
 
 typedef struct CgrtScene CgrtScene;
@@ -96,6 +99,20 @@ int cgrt_num_subnodes(const CgrtScene* scene);
 /* Scheduling of the fused primary-frame kernel (results are identical; tested): 0 = one wave per 8x8 tile,
  * 1 = persistent waves that pull tiles from per-XCD queues and refill finished lanes.  Process-wide. */
 int cgrt_set_primary_mode(int mode);
+/* Certified walk (no counterpart upstream; DESIGN.md "Certified walk").  The exact walk takes every step of the
+ * reference's ordered descent (bvh.cpp:572-758) because its culling quirks are part of the result.  A scene may also
+ * carry a "fast tree" (a 4-wide tree over the reference LEAVES) and per-leaf box paths: a ray then searches the fast
+ * tree with conservative tests, and its answer is kept only if a certificate holds -- unique strict minimum, no
+ * origin-on-plane acceptance, and every box the reference tests on its way to that leaf is entered at the final t
+ * (the reference's own box arithmetic); any other ray is walked exactly.  Results are identical either way (tested).
+ *   cgrt_set_fast_tree: process-wide, for scenes created afterwards: -1 (default) = build it when the reference tree
+ *     ends in fat leaves (an in-leaf accelerator exists), 0 = never, 1 = whenever the structures allow it.
+ *   cgrt_scene_set_walk: per scene, 1 = certified walk (needs the fast tree: CGRT_E_ARG otherwise), 0 = exact walk only.
+ *     Not to be changed while launches of the scene are being issued from other threads.
+ *   cgrt_scene_walk: the current setting (1 / 0). */
+int cgrt_set_fast_tree(int mode);
+int cgrt_scene_set_walk(CgrtScene* scene, int certified);
+int cgrt_scene_walk(const CgrtScene* scene);
 
 /* BoundingVolumeHierarchy::numLevels() (bvh.cpp:214-224). */
 int cgrt_num_levels(const CgrtScene* scene);
