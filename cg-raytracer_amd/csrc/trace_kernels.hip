@@ -18,16 +18,17 @@ template <bool COUNT, bool FAST>
 __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                         unsigned long long* counters) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
     LaneCounters cnt;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    if (active) primary_ray(C, F.W, F.H, x, y, o, d);
+    float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
+    uint32_t hit_rec = REF_NONE;
+    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
     if (active) {
-        F3 o, d;
-        primary_ray(C, F.W, F.H, x, y, o, d);
-        float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
-        uint32_t hit_rec = REF_NONE;
-        walk_tree<COUNT, FAST>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
         const size_t pix = (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
@@ -42,6 +43,7 @@ template <bool FAST>
 __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
                                                 float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
@@ -49,13 +51,11 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
     CgrtHitDev h;
     h.hit = 0;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0), nn = f3(0, 0, 0);
-    if (active) {
-        primary_ray(C, F.W, F.H, x, y, o, d);
-        float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
-        uint32_t hit_rec = REF_NONE;
-        walk_tree<false, FAST>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
-        resolve_hit(S, o, d, t, hit_rec, true, h, nn);
-    }
+    if (active) primary_ray(C, F.W, F.H, x, y, o, d);
+    float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
+    uint32_t hit_rec = REF_NONE;
+    walk_tree<false, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    if (active) resolve_hit(S, o, d, t, hit_rec, true, h, nn);
     // one atomic per workgroup (same-address atomics serialise at the L2); the workgroup's LDS is only released when its
     // last wave ends anyway, so waiting for it here costs no occupancy
     const bool keep = active && h.hit != 0;
@@ -105,6 +105,7 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                                             unsigned long long* counters, const uint32_t* __restrict__ dcount) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
     const unsigned long long i = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
     if (dcount) {
         const unsigned long long present = *dcount;
@@ -112,14 +113,17 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
     }
     const bool active = i < n;
     LaneCounters cnt;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    float t = 0.0f;
     if (active) {
         const float* r = rays + 7 * i;
-        const F3 o = f3(r[0], r[1], r[2]), d = f3(r[3], r[4], r[5]);
-        float t = r[6];
-        uint32_t hit_rec = REF_NONE;
-        walk_tree<COUNT, FAST>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
-        finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
+        o = f3(r[0], r[1], r[2]);
+        d = f3(r[3], r[4], r[5]);
+        t = r[6];
     }
+    uint32_t hit_rec = REF_NONE;
+    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    if (active) finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
     if (COUNT) flush_counters(cnt, active, counters);
 }
 
@@ -133,6 +137,7 @@ template <bool ANYHIT, bool FAST>
 __global__ CGRT_LB void k_soft_shadow(SceneDev S, SoftDev Q, const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits,
                                       const int* __restrict__ item_pixels, unsigned long long nthreads, uint32_t* __restrict__ lit) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
     const unsigned long long g = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
     const bool in = g < nthreads;
     const unsigned long long key = in ? g / Q.samples : 0ull;  // item * nlights + l
@@ -141,18 +146,20 @@ __global__ CGRT_LB void k_soft_shadow(SceneDev S, SoftDev Q, const float* __rest
     const uint32_t l = (uint32_t)(key - item * Q.nlights);
     bool is_lit = false;
     const bool live = in && hits[item].hit != 0;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    float t = 0.0f;
     if (live) {
         const float* r = rays + 7 * item;
         const F3 pointOn = add(f3(r[0], r[1], r[2]), scale(f3(r[3], r[4], r[5]), hits[item].t));
         const float* L = Q.lights + 7 * l;
         const float* u = Q.units + 3ull * soft_sample_index(Q.seed, (uint32_t)item_pixels[item], Q.level, l, smp, Q.nunits);
-        F3 o, d;
-        float t;
         soft_shadow_ray(pointOn, f3(L[0], L[1], L[2]), L[3], f3(u[0], u[1], u[2]), o, d, t);
-        const float lightT = t;
-        uint32_t hit_rec = REF_NONE;
-        LaneCounters cnt;
-        walk_tree<false, FAST, ANYHIT>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
+    }
+    const float lightT = t;
+    uint32_t hit_rec = REF_NONE;
+    LaneCounters cnt;
+    walk_tree<false, FAST, ANYHIT>(S, live, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    if (live) {
         bool hit = hit_rec != REF_NONE;
         if (!ANYHIT || !hit) {  // spheres come after the meshes in BoundingVolumeHierarchy::intersect (bvh.cpp:875-880)
             for (uint32_t k = 0; k < S.nspheres; k++) {

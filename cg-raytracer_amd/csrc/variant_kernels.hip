@@ -19,20 +19,19 @@ template <bool FAST>
 __global__ CGRT_LB void k_trace_primary_stamped(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits,
                                                 unsigned long long* __restrict__ stamps) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
+    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = blockIdx.x * (CGRT_BLOCK / 64) + (threadIdx.x >> 6);
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
     LaneCounters cnt;
-    if (active) {
-        F3 o, d;
-        primary_ray(C, F.W, F.H, x, y, o, d);
-        float t = 3.402823466e+38f;
-        uint32_t hit_rec = REF_NONE;
-        walk_tree<true, FAST>(S, o, d, t, hit_rec, s_stk + threadIdx.x, cnt);
-        finish_ray(S, o, d, t, hit_rec, hits + ((size_t)y * F.W + x), nullptr);
-    }
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    if (active) primary_ray(C, F.W, F.H, x, y, o, d);
+    float t = 3.402823466e+38f;
+    uint32_t hit_rec = REF_NONE;
+    walk_tree<true, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    if (active) finish_ray(S, o, d, t, hit_rec, hits + ((size_t)y * F.W + x), nullptr);
     const unsigned long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long nactive = __popcll(__ballot(active));
     uint32_t v[11] = {cnt.inner, cnt.leaf, cnt.tri, cnt.sub, cnt.w_inner, cnt.w_sub, cnt.w_tri, cnt.inner, cnt.leaf, cnt.tri, cnt.sub};

@@ -83,40 +83,246 @@ __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W,
     return ok;
 }
 
-// Precondition: walk_begin(S, W) returned true, S.fast_root != REF_NONE, W.P.regular and W.R.fd.
-// Returns true when (W.t, W.hit_rec) now hold the reference's result; false: W is untouched, take the exact walk.
+// ---------------------------------------------------------------------------------------------
+// Quad tail.  A frame ends with its hardest waves, and those spend most of their life with a handful of live rays whose
+// lanes take turns (a node body for these, a run body for those) on an otherwise idle SIMD.  The certified search is
+// order-free, so once a wave is down to <= 16 live rays each of them is spread over the four lanes of a quad: per round
+// the quad takes up to four entries off the ray's stack (it stays in the owner's LDS slice), each lane steps through
+// one of them -- a node's four boxes, or a run's triangles -- and the survivors go back on the stack, nearest last.  The
+// four entries cannot cull one another inside a round (a little extra work), everything else is the lane-per-ray search:
+// same boxes, same triangle arithmetic, the minimum (with its tie and on-plane flags) reduced over the quad.
+// A stack that would outgrow its slice gives the ray up (-> exact walk), like any other missing certificate.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(const uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(const float v) {
+    return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
+}
+#define CGRT_QP_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define CGRT_QP_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define CGRT_QP_BCAST(i) ((i) * 0x55)  // quad_perm [i,i,i,i]
+#ifndef CGRT_QUAD_TAIL_RAYS
+#define CGRT_QUAD_TAIL_RAYS 16  // a wave with at most this many live rays switches to the quad tail (0: never)
+#endif
+
+struct QuadState {  // quad-uniform: every lane of a quad holds the same values
+    float best_t;
+    uint32_t best_rec;
+    bool tie, onp, failed;
+};
+
+// merge of two scan states that started from the same state (associative, commutative)
+__device__ __forceinline__ void quad_merge(float& bt, uint32_t& br, bool& tie, const float obt, const uint32_t obr, const bool otie) {
+    const bool take = obt < bt;
+    const bool same = (obt == bt);
+    tie = take ? otie : (same ? (tie || otie || (obr != br)) : tie);
+    br = take ? obr : br;
+    bt = take ? obt : bt;
+}
+
+// live: lanes that carry an unfinished ray (<= 16 of them); their state is (F, cur, sp) with the stack in their own slice.
+// On return the owners hold their ray's final FastScan and `failed`.
+template <bool COUNT, bool ANYHIT>
+__device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long long live, const bool mine, const Walk& W, FastScan& F,
+                                          uint32_t cur, int sp, bool& failed, uint32_t* __restrict__ s_stk_block, uint32_t* __restrict__ s_map,
+                                          LaneCounters& cnt) {
+    const int lane = threadIdx.x & 63;
+    const int myrank = __popcll(live & ((1ull << lane) - 1ull));
+    uint32_t* __restrict__ my = s_stk_block + threadIdx.x;
+    if (mine) {
+        if (cur != REF_NONE) {  // the node or run the lane stands on goes back on its stack
+            my[sp * CGRT_BLOCK] = cur;
+            sp += 1;
+        }
+        s_map[myrank] = (uint32_t)lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int Q = lane >> 2, q = lane & 3;
+    const bool valid = Q < (int)__popcll(live);
+    const int src = valid ? (int)s_map[Q] : lane;
+    // the owner's ray, broadcast to its quad (all 64 lanes take part in the shuffles)
+    RayPre P;
+    P.inv = f3(__shfl(W.P.inv.x, src, 64), __shfl(W.P.inv.y, src, 64), __shfl(W.P.inv.z, src, 64));
+    P.oin = f3(__shfl(W.P.oin.x, src, 64), __shfl(W.P.oin.y, src, 64), __shfl(W.P.oin.z, src, 64));
+    P.oif = f3(__shfl(W.P.oif.x, src, 64), __shfl(W.P.oif.y, src, 64), __shfl(W.P.oif.z, src, 64));
+    const int sg = __shfl((int)((W.P.sx ? 1 : 0) | (W.P.sy ? 2 : 0) | (W.P.sz ? 4 : 0)), src, 64);
+    P.sx = (sg & 1) != 0;
+    P.sy = (sg & 2) != 0;
+    P.sz = (sg & 4) != 0;
+    P.regular = true;
+    const F3 o = f3(__shfl(W.o.x, src, 64), __shfl(W.o.y, src, 64), __shfl(W.o.z, src, 64));
+    const F3 d = f3(__shfl(W.d.x, src, 64), __shfl(W.d.y, src, 64), __shfl(W.d.z, src, 64));
+    QuadState G;
+    G.best_t = __shfl(F.best_t, src, 64);
+    G.best_rec = __shfl(F.best_rec, src, 64);
+    const int fl = __shfl((int)((F.tie ? 1 : 0) | (F.onp ? 2 : 0)), src, 64);
+    G.tie = (fl & 1) != 0;
+    G.onp = (fl & 2) != 0;
+    G.failed = false;
+    const int osp = __shfl(sp, src, 64);  // (unconditional: a shuffle only sees lanes that execute it)
+    int qsp = valid ? osp : 0;
+    uint32_t* __restrict__ stk = s_stk_block + ((threadIdx.x & ~63u) + (uint32_t)src);  // the owner's LDS slice
+    const float inf = __builtin_inff();
+    while (__any(qsp > 0)) {
+        // entries this round: up to four, fewer when the survivors (at most 4 per node) might not fit
+        int n = qsp < 4 ? qsp : 4;
+        while (n > 0 && qsp + 3 * n > CGRT_STACK_SLOTS) n -= 1;
+        if (qsp > 0 && n == 0) {
+            G.failed = true;
+            qsp = 0;
+        }
+        const bool has = q < n;
+        const uint32_t ref = has ? stk[(qsp - 1 - q) * CGRT_BLOCK] : REF_NONE;
+        qsp -= n;
+        uint32_t r0 = REF_NONE, r1 = REF_NONE, r2 = REF_NONE, r3 = REF_NONE;
+        int c = 0;
+        float lt = G.best_t;
+        uint32_t lr = G.best_rec;
+        bool ltie = G.tie, lonp = false;
+        if (has && !(ref & REF_LEAF)) {  // a 4-wide node: its four boxes, hit children sorted near to far
+            if (COUNT) {
+                cnt.sub++;
+                if (first_active_lane()) cnt.w_sub++;
+            }
+            const float4* g = reinterpret_cast<const float4*>(S.subnodes + ref);
+            const float4 a0 = g[0], b0 = g[1], c0 = g[2];
+            const uint2 m0 = *reinterpret_cast<const uint2*>(g + 3);
+            const float4 a1 = g[4], b1 = g[5], c1 = g[6];
+            const uint2 m1 = *reinterpret_cast<const uint2*>(g + 7);
+            float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
+            slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
+            slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);
+            slab_cons(P, f3(a1.x, a1.y, a1.z), f3(a1.w, b1.x, b1.y), tn2, tf2);
+            slab_cons(P, f3(b1.z, b1.w, c1.x), f3(c1.y, c1.z, c1.w), tn3, tf3);
+            const float tc = fmaxf(G.best_t, 0.0f);
+            float k0 = ((tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc)) ? tn0 : inf;
+            float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
+            float k2 = ((tn2 <= tf2) && (tf2 >= 0.0f) && (tn2 <= tc)) ? tn2 : inf;
+            float k3 = ((tn3 <= tf3) && (tf3 >= 0.0f) && (tn3 <= tc)) ? tn3 : inf;
+            r0 = m0.x, r1 = m0.y, r2 = m1.x, r3 = m1.y;
+#define CGRT_CSWAP(ka, ra, kb, rb)          \
+{                                       \
+    const bool sw = kb < ka;            \
+    const float kt = sw ? kb : ka;      \
+    const uint32_t rt = sw ? rb : ra;   \
+    kb = sw ? ka : kb;                  \
+    rb = sw ? ra : rb;                  \
+    ka = kt;                            \
+    ra = rt;                            \
+}
+            CGRT_CSWAP(k0, r0, k1, r1)
+            CGRT_CSWAP(k2, r2, k3, r3)
+            CGRT_CSWAP(k0, r0, k2, r2)
+            CGRT_CSWAP(k1, r1, k3, r3)
+            CGRT_CSWAP(k1, r1, k2, r2)
+#undef CGRT_CSWAP
+            c = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);  // hit children are r0 .. r(c-1)
+        }
+        if (has && (ref & REF_LEAF)) {  // a run of records
+            FastScan L;
+            L.best_t = G.best_t;
+            L.best_rec = G.best_rec;
+            L.tie = G.tie;
+            L.onp = false;
+            fast_test_run<COUNT>(S, run_first(ref), run_count(ref), o, d, L, cnt);
+            lt = L.best_t;
+            lr = L.best_rec;
+            ltie = L.tie;
+            lonp = L.onp;
+        }
+        // survivors back on the stack: lane 0 held the top entry, so its children go on top (pushed last), and inside a
+        // lane the nearest child last
+        const int c0q = (int)dpp_u32<CGRT_QP_BCAST(0)>((uint32_t)c), c1q = (int)dpp_u32<CGRT_QP_BCAST(1)>((uint32_t)c);
+        const int c2q = (int)dpp_u32<CGRT_QP_BCAST(2)>((uint32_t)c), c3q = (int)dpp_u32<CGRT_QP_BCAST(3)>((uint32_t)c);
+        const int off = (q < 3 ? c3q : 0) + (q < 2 ? c2q : 0) + (q < 1 ? c1q : 0);
+        int pos = qsp + off;
+        if (c > 3) stk[(pos++) * CGRT_BLOCK] = r3;
+        if (c > 2) stk[(pos++) * CGRT_BLOCK] = r2;
+        if (c > 1) stk[(pos++) * CGRT_BLOCK] = r1;
+        if (c > 0) stk[(pos++) * CGRT_BLOCK] = r0;
+        qsp += c0q + c1q + c2q + c3q;
+        // the scan state, reduced over the quad
+        {
+            float ot = dpp_f32<CGRT_QP_XOR1>(lt);
+            uint32_t orr = dpp_u32<CGRT_QP_XOR1>(lr);
+            uint32_t ofl = dpp_u32<CGRT_QP_XOR1>((ltie ? 1u : 0u) | (lonp ? 2u : 0u));
+            quad_merge(lt, lr, ltie, ot, orr, (ofl & 1u) != 0);
+            lonp = lonp || ((ofl & 2u) != 0);
+            ot = dpp_f32<CGRT_QP_XOR2>(lt);
+            orr = dpp_u32<CGRT_QP_XOR2>(lr);
+            ofl = dpp_u32<CGRT_QP_XOR2>((ltie ? 1u : 0u) | (lonp ? 2u : 0u));
+            quad_merge(lt, lr, ltie, ot, orr, (ofl & 1u) != 0);
+            lonp = lonp || ((ofl & 2u) != 0);
+        }
+        G.best_t = lt;
+        G.best_rec = lr;
+        G.tie = ltie;
+        G.onp = G.onp || lonp;
+        if (ANYHIT && (G.best_rec != REF_NONE || G.onp)) qsp = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round reads what the other lanes of the quad just wrote
+    }
+    // results back to the owners (quad `myrank`, any of its lanes)
+    const int ql = 4 * myrank;
+    const float r_t = __shfl(G.best_t, ql, 64);
+    const uint32_t r_rec = __shfl(G.best_rec, ql, 64);
+    const int r_fl = __shfl((int)((G.tie ? 1 : 0) | (G.onp ? 2 : 0) | (G.failed ? 4 : 0)), ql, 64);
+    if (mine) {
+        F.best_t = r_t;
+        F.best_rec = r_rec;
+        F.tie = (r_fl & 1) != 0;
+        F.onp = (r_fl & 2) != 0;
+        failed = (r_fl & 4) != 0;
+    }
+}
+
+// The certified search for a whole wave.  `alive`: the lane carries a ray that passed the root gate, lies inside both
+// envelopes (W.P.regular, W.R.fd) and wants the certified walk; the other lanes only help in the quad tail.  Must be called
+// by all 64 lanes (wave-uniform control flow).  Returns, per alive lane, true when (W.t, W.hit_rec) now hold the reference's
+// result; false: W is untouched, take the exact walk.
 // ANYHIT (the caller only needs the hit FLAG): the search stops at the first accepted triangle; if that triangle's path is
 // certified the reference's flag is set too -- had the reference accepted nothing, ray.t would still be the initial one and
 // it would reach that leaf and accept the triangle.
 template <bool COUNT, bool ANYHIT>
-__device__ __forceinline__ bool walk_fast(const SceneDev& S, Walk& W, uint32_t* __restrict__ stk, LaneCounters& cnt) {
+__device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool alive, Walk& W, uint32_t* __restrict__ s_stk_block,
+                                               uint32_t* __restrict__ s_map, LaneCounters& cnt) {
+    uint32_t* __restrict__ stk = s_stk_block + threadIdx.x;
     const F3 o = W.o, d = W.d;
     FastScan F;
     F.best_t = W.t;
     F.best_rec = REF_NONE;
     F.tie = false;
     F.onp = false;
-    uint32_t cur = S.fast_root;
+    uint32_t cur = alive ? S.fast_root : REF_NONE;
     int sp = 0;
-    bool done = false;
-    while (!done) {
-        if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
-        if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
-        if (cur != REF_NONE && (cur & REF_LEAF)) {
-            fast_test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, F, cnt);
-            cur = REF_NONE;
-            if (ANYHIT && (F.best_rec != REF_NONE || F.onp)) done = true;
+    bool done = !alive, failed = false;
+    for (;;) {
+        const unsigned long long live = __ballot(!done);
+        if (live == 0ull) break;
+        if (CGRT_QUAD_TAIL_RAYS > 0 && __popcll(live) <= CGRT_QUAD_TAIL_RAYS) {
+            quad_tail<COUNT, ANYHIT>(S, live, !done, W, F, cur, sp, failed, s_stk_block, s_map, cnt);
+            break;
         }
-        if (cur == REF_NONE && !done) {
-            if (sp > 0) {
-                sp -= 1;
-                cur = stk[sp * CGRT_BLOCK];
-            } else {
-                done = true;
+        if (!done) {
+            if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
+            if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
+            if (cur != REF_NONE && (cur & REF_LEAF)) {
+                fast_test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, F, cnt);
+                cur = REF_NONE;
+                if (ANYHIT && (F.best_rec != REF_NONE || F.onp)) done = true;
+            }
+            if (cur == REF_NONE && !done) {
+                if (sp > 0) {
+                    sp -= 1;
+                    cur = stk[sp * CGRT_BLOCK];
+                } else {
+                    done = true;
+                }
             }
         }
     }
-    if (F.onp || F.tie) return false;
+    if (!alive || failed || F.onp || F.tie) return false;
     if (F.best_rec != REF_NONE) {
         if (!path_certified<COUNT>(S, W, F.best_rec, F.best_t, cnt)) return false;
         W.t = F.best_t;
@@ -125,28 +331,29 @@ __device__ __forceinline__ bool walk_fast(const SceneDev& S, Walk& W, uint32_t* 
     return true;
 }
 
-// BoundingVolumeHierarchy::intersect's mesh part (bvh.cpp:870-875) for one ray: root gate, then the certified walk when the
-// scene has a fast tree and the ray lies inside both envelopes (RayPre::regular, RayFast::fd), the exact walk otherwise
-// or when no certificate was obtained.
+// BoundingVolumeHierarchy::intersect's mesh part (bvh.cpp:870-875) for the rays of a wave (one per `active` lane; call
+// with all 64 lanes): root gate, then the certified walk when the scene has a fast tree and the ray lies inside both
+// envelopes (RayPre::regular, RayFast::fd), the exact walk otherwise or when no certificate was obtained.
 // ANYHIT (exact walk): stop after the first leaf that accepted a triangle.  The walk up to there is the reference's, so the
 // hit FLAG is the reference's (some acceptance happens upstream iff one happens in the first leaf that has one); t and the
 // record are those of that leaf, not the final ones.
 template <bool COUNT, bool FAST, bool ANYHIT = false>
-__device__ __forceinline__ void walk_tree(const SceneDev& S, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
-                                          uint32_t* __restrict__ stk, LaneCounters& cnt) {
+__device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
+                                          uint32_t* __restrict__ s_stk_block, uint32_t* __restrict__ s_map, LaneCounters& cnt) {
     Walk W;
     W.o = o;
     W.d = d;
     W.t = t;
-    if (walk_begin(S, W)) {
-        if (COUNT) cnt.entered++;
-        bool certified = false;
-        if (FAST && W.P.regular && W.R.fd) {
-            certified = walk_fast<COUNT, ANYHIT>(S, W, stk, cnt);
-            if (COUNT && !certified) cnt.fallback++;
-        }
-        if (!certified) walk_tree_unified<COUNT, ANYHIT>(S, W, stk, cnt);
+    W.hit_rec = REF_NONE;
+    const bool entered = active && walk_begin(S, W);
+    if (COUNT && entered) cnt.entered++;
+    bool certified = false;
+    if (FAST) {
+        const bool eligible = entered && W.P.regular && W.R.fd;
+        if (__any(eligible)) certified = walk_fast_wave<COUNT, ANYHIT>(S, eligible, W, s_stk_block, s_map, cnt);
+        if (COUNT && eligible && !certified) cnt.fallback++;
     }
+    if (entered && !certified) walk_tree_unified<COUNT, ANYHIT>(S, W, s_stk_block + threadIdx.x, cnt);
     t = W.t;
     hit_rec = W.hit_rec;
 }
