@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- primary Mrays/s + achieved algorithmic GB/s of the BVH traversal + ray/triangle path on the
-dragon stand-in at 1920x1080 (BASELINE.json metric), one process per GPU.
+dragon stand-in (BASELINE.json metric), one process per GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W                       # headline: 1920x1080 (BASELINE config 4)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+                                                                       # BASELINE config 5: ONE 3840x2160 frame split over N ranks
 
-A step = one pass of the hot path (fused primary-ray generation + BoundingVolumeHierarchy::intersect for
-every pixel the rank owns) with the scene resident in HBM.  N > 1: the frame grows with N (weak scaling,
-tiling.frame_for_world), 8x8 tiles are dealt round-robin to ranks, no data-path collective; the timed
-region is bracketed by barrier + synchronize and the MAX over ranks is taken.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path (fused primary-ray generation + BoundingVolumeHierarchy::intersect for every pixel
+the rank owns) with the scene resident in HBM.  The frame is cut into 64x64-pixel super-tiles, super-tile i belongs to
+rank i % N, the scene is replicated, no data-path collective exists; the timed region is bracketed by barrier +
+synchronize and the MAX over ranks is taken.  Rank 0 prints ONE JSON line.
+
+Scaling modes (N > 1): "strong" (default) = the fixed 3840x2160 frame of BASELINE.json's config 5 -- the reference's one
+parallel construct is rows of one frame (main.cpp:653-656); "weak" (--scaling weak) = the frame grows with N so that
+per-GPU work stays at 1920x1080.  `--scaling strong` at N = 1 renders the config-5 frame on one GPU (the base of the curve).
+Other workloads: --workload shaded (cgrt_render: primary + shadow + mirror rays, the reference's whole frame),
+--tris 87000 (the report's dragon size), --obj PATH (a user-supplied mesh, e.g. the real dragon.obj).
 """
 from __future__ import annotations
 
@@ -25,45 +32,75 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CONFIG5 = (3840, 2160)  # BASELINE.json configs[4]
 
 
-def cpu_baseline(pkg, sd, cam, W, H, budget_s=15.0):
-    """The oracle (CPU restatement of the reference algorithm, kind "port") timed on this box's host cores
-    on a bounded sample of the same frame: a centred block of rows sized for ~budget_s of work, run as one
-    `omp parallel for` over rows exactly like main.cpp:653-656, wall time by std::chrono like :791-797."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, cam, W, H, budget_s=12.0):
+    """The oracle (CPU restatement of the reference algorithm, kind "port") timed on this box's host cores on a bounded
+    sample of the same frame: a centred block of rows, run as one `omp parallel for` over rows exactly like
+    main.cpp:653-656, wall time by std::chrono like :791-797.  Two builds, as SURVEY.md section 8(d) asks: -O2 and -O0
+    (the reference's de-facto build type, CMake sets none); each: one warm-up, then best of 3.  `value` is the -O2 figure."""
     orc = entry.load_oracle()
     threads = os.cpu_count() or 1
-    t0 = time.time()
-    o = orc.OracleScene(sd)
-    build_s = time.time() - t0
-    probe = min(H, 2 * threads)
-    y0 = (H - probe) // 2
-    s, _ = o.trace_primary_timed(cam, W, H, y0=y0, y1=y0 + probe, threads=threads)
-    blk = int(max(probe, min(H, probe * budget_s / max(s, 1e-6))))
-    y0 = (H - blk) // 2
-    s, _ = o.trace_primary_timed(cam, W, H, y0=y0, y1=y0 + blk, threads=threads)
+    legs = {}
+    sample = ""
+    for o0 in (False, True):
+        t0 = time.time()
+        o = orc.OracleScene(sd, o0=o0)
+        build_s = time.time() - t0
+        probe = min(H, 2 * threads)
+        y0 = (H - probe) // 2
+        s, _ = o.trace_primary_timed(cam, W, H, y0=y0, y1=y0 + probe, threads=threads)  # warm-up + sizing probe
+        per_leg = budget_s / 2 / 3  # three timed repetitions per build inside the budget
+        blk = int(max(probe, min(H, probe * per_leg / max(s, 1e-6))))
+        y0 = (H - blk) // 2
+        best = min(o.trace_primary_timed(cam, W, H, y0=y0, y1=y0 + blk, threads=threads)[0] for _ in range(3))
+        legs["O0" if o0 else "O2"] = {"Mrays_per_s": round(blk * W / best / 1e6, 4), "rows": blk, "best_of_3_s": round(best, 3),
+                                      "oracle_bvh_build_s": round(build_s, 2)}
+        if not o0:
+            sample = (f"rows {y0}..{y0 + blk} ({blk * W} primary rays) of the same {W}x{H} frame, omp parallel for over rows, "
+                      f"one warm-up then best of 3; -O0 leg sized the same way")
+        o.close()
     return {
-        "value": round(blk * W / s / 1e6, 4),
+        "value": legs["O2"]["Mrays_per_s"],
         "unit": "Mrays/s",
         "cores": threads,
+        "cpu_model": cpu_model(),
         "kind": "port",
-        "sample": f"rows {y0}..{y0 + blk} ({blk * W} primary rays) of the same {W}x{H} frame in {s:.1f}s, "
-                  f"g++ -O2 oracle, omp parallel for over rows; oracle BVH build {build_s:.1f}s not included",
+        "sample": sample,
+        "builds": legs,
     }
 
 
 def read_traffic(workload: str):
     """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic_latest.json, written by
-    tools/profile_round.sh on the GPU box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
-    correction applied as MI355X_MICROARCH.md prescribes).  None when no pass matches this workload."""
+    tools/profile_round.sh on the GPU box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes).  NOT measured by this run: returned with its source so that the reader can tell; None
+    when no pass matches this workload and walk."""
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
     try:
         tj = json.load(open(tpath))
         if tj.get("workload") == workload:
-            return tj.get("hbm_bytes_per_launch")
+            return tj.get("hbm_bytes_per_launch"), f"profiles/hbm_traffic_latest.json ({tj.get('source', 'PMC pass')}), not measured by this run"
     except Exception:
         pass
-    return None
+    return None, None
+
+
+def algorithmic_bytes(cnt, rs):
+    """record bytes of every visit + the result store; 24 B per certificate box."""
+    return (cnt["inner_visits"] * rs["node"] + cnt["tri_tests"] * rs["tri"] + cnt["sub_visits"] * rs["sub"] + cnt["cert_boxes"] * 24
+            + cnt["rays"] * rs["hit"])
 
 
 def main():
@@ -71,11 +108,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--tris", type=int, default=800_000, help="triangles of the procedural dragon stand-in")
+    ap.add_argument("--tris", type=int, default=800_000, help="triangles of the procedural dragon stand-in (87000 = the report's size)")
+    ap.add_argument("--obj", type=str, default="", help="load this OBJ (centred + unit-scaled like scene.cpp:42) instead of the stand-in")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="auto: N = 1 -> the 1920x1080 headline frame, N > 1 -> strong (fixed 3840x2160 frame, BASELINE config 5)")
+    ap.add_argument("--workload", choices=["primary", "shaded"], default="primary",
+                    help="primary = fused ray generation + intersect (the headline); shaded = cgrt_render, depth 2, all rays of the frame")
+    ap.add_argument("--walk", choices=["auto", "exact", "certified"], default="auto",
+                    help="auto = the scene's default (certified when it carries a fast tree), exact = the reference's steps only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (config-5 frame on one GPU, 87 K dragon) at N = 1")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="independent frames kept in flight on separate HIP streams (1 = strictly back to back, the reported default)")
     args = ap.parse_args()
@@ -108,31 +153,36 @@ def main():
     pkg = entry.load_package()
     from cg_raytracer_amd import tiling
 
-    W, H = tiling.frame_for_world(world)
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "headline")
+    if scaling == "strong":
+        W, H = CONFIG5
+    elif scaling == "weak":
+        W, H = tiling.frame_for_world(world)
+    else:
+        W, H = tiling.BASE_W, tiling.BASE_H
     if args.width and args.height:
         W, H = args.width, args.height
     if os.environ.get("CGRT_PRIMARY_MODE"):  # experiment knob: 0 = wave per tile, 1 = persistent waves with lane refill
         pkg.set_primary_mode(int(os.environ["CGRT_PRIMARY_MODE"]))
     if os.environ.get("CGRT_SUB_LEAF"):  # experiment knob: triangles per in-leaf accelerator run
         pkg.set_leaf_accel(True, int(os.environ["CGRT_SUB_LEAF"]))
-    sd = pkg.scenes.make_dragon(args.tris)
+    if args.obj:
+        sd = pkg.host_load_obj(args.obj, normalize=True)
+        scene_name = f"{os.path.basename(args.obj)} ({sd.ntris} tris, {sd.nmesh} mesh(es))"
+        data = f"user-supplied OBJ {os.path.basename(args.obj)}"
+    else:
+        sd = pkg.scenes.make_dragon(args.tris)
+        scene_name = f"dragon stand-in {sd.ntris} tris (1 mesh, 12-level reference BVH)"
+        data = "synthetic (procedural dragon stand-in: data/dragon.obj is absent from the reference checkout)"
     cam = pkg.scenes.default_camera(W, H)
     t0 = time.time()
     scene = pkg.Scene(sd, device=local_rank)
     setup_s = time.time() - t0
+    if args.walk != "auto":
+        scene.set_walk(args.walk == "certified")
+    walk = "certified (fast tree + certificate, exact fallback)" if scene.walk() else "exact"
 
-    nfl = max(1, args.frames_in_flight)
-    hits_bufs = [torch.empty(W * H * 4, dtype=torch.int32, device="cuda") for _ in range(nfl)]  # CgrtHit x W*H each, in HBM
-    hits = hits_bufs[0]
     main_stream = torch.cuda.current_stream()
-    streams = [main_stream] + [torch.cuda.Stream() for _ in range(nfl - 1)]
-    stream = main_stream.cuda_stream
-    step_no = [0]
-
-    def step():
-        k = step_no[0] % nfl
-        step_no[0] += 1
-        scene.trace_primary_device(cam, W, H, hits_bufs[k].data_ptr(), rank=rank, nranks=world, stream=streams[k].cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -140,73 +190,183 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_start = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    for st in streams[1:]:
-        main_stream.wait_stream(st)  # the closing event covers every frame in flight
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t_start
-    kern_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: avg launch duration
+    def timed(step_fn, steps, warmup, streams=()):
+        """W untimed steps, then exactly K steps between barrier + synchronize; returns (wall seconds, event ms per step)."""
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_start = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            step_fn()
+        for st in streams:
+            main_stream.wait_stream(st)  # the closing event covers every frame in flight
+        ev1.record()
+        barrier()
+        return time.perf_counter() - t_start, ev0.elapsed_time(ev1) / steps  # HIP events on the launch stream
 
-    my_rays = tiling.owned_pixels(W, H, rank, world)
-    cnt = scene.count_primary(cam, W, H, rank=rank, nranks=world)  # instrumented launch, outside the timed region
-    assert cnt["rays"] == my_rays, (cnt, my_rays)
+    def primary_runner(sc, cam_, W_, H_, rank_, world_, nfl=1):
+        bufs = [torch.empty(W_ * H_ * 4, dtype=torch.int32, device="cuda") for _ in range(nfl)]  # CgrtHit x W*H each, in HBM
+        streams = [main_stream] + [torch.cuda.Stream() for _ in range(nfl - 1)]
+        k = [0]
+
+        def step():
+            i = k[0] % nfl
+            k[0] += 1
+            sc.trace_primary_device(cam_, W_, H_, bufs[i].data_ptr(), rank=rank_, nranks=world_, stream=streams[i].cuda_stream)
+
+        return step, streams[1:], bufs
+
     rs = pkg.record_sizes()
-    alg_bytes = cnt["inner_visits"] * rs["node"] + cnt["tri_tests"] * rs["tri"] + cnt["sub_visits"] * rs["sub"] + cnt["rays"] * rs["hit"]
-
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if dist is not None:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall_max = float(wall_t.item())
-    total_rays = W * H
-    if rank == 0:
-        ms_per_step = wall_max / args.steps * 1e3
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = read_traffic(f"dragon{sd.ntris}_{W}x{H}")
+    nfl = max(1, args.frames_in_flight)
+    out = None
+    if args.workload == "primary":
+        step, extra_streams, bufs = primary_runner(scene, cam, W, H, rank, world, nfl)
+        wall, kern_ms = timed(step, args.steps, args.warmup, extra_streams)
+        my_rays = tiling.owned_pixels(W, H, rank, world)
+        cnt = scene.count_primary(cam, W, H, rank=rank, nranks=world)  # instrumented launch, outside the timed region
+        assert cnt["rays"] == my_rays, (cnt, my_rays)
+        alg_bytes = algorithmic_bytes(cnt, rs)
+        # the gather of SURVEY.md section 8(e): this rank's hits device -> pinned host, one async copy, timed on its own
+        host = torch.empty(W * H * 4, dtype=torch.int32).pin_memory()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        host.copy_(bufs[0], non_blocking=True)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        per_rank = [my_rays]
+        walls = torch.tensor([wall, gather_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(walls, op=dist.ReduceOp.MAX)
+            lst = [None] * world
+            dist.all_gather_object(lst, my_rays)
+            per_rank = [int(x) for x in lst]
+        wall_max, gather_max = float(walls[0].item()), float(walls[1].item())
+        total_rays = W * H
+        n1_same = None
+        if world > 1 and rank == 0 and scaling != "weak":
+            # the base of the strong-scaling curve, measured by rank 0 alone on the whole frame after the timed region
+            s1, _, _ = primary_runner(scene, cam, W, H, 0, 1)
+            for _ in range(3):
+                s1()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                s1()
+            torch.cuda.synchronize()
+            n1_same = total_rays / ((time.perf_counter() - t1) / 10) / 1e6
+        if rank == 0:
+            ms_per_step = wall_max / args.steps * 1e3
+            achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+            traffic, traffic_src = read_traffic(f"dragon{sd.ntris}_{W}x{H}_{'certified' if scene.walk() else 'exact'}")
+            tree = max(1, cnt["tree_rays"])
+            out = {
+                "metric": (f"primary Mrays/sec (BVH traversal + ray-triangle, {'user OBJ' if args.obj else 'dragon stand-in'} @{W}x{H}"
+                           + (f", one frame split over {world} GPUs, strong scaling" if world > 1 and scaling == "strong" else
+                              (f", frame grown with {world} GPUs, weak scaling" if world > 1 else "")) + ")"),
+                "value": round(total_rays / (wall_max / args.steps) / 1e6, 3),
+                "unit": "Mrays/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 4),
+                "higher_is_better": True,
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": data,
+                "config": {
+                    "workload": f"{scene_name}, {W}x{H} primary rays, reference default camera, 64x64-pixel super-tiles dealt i % {world} to "
+                                f"{world} rank(s), {walk} walk",
+                    "rays_per_step": total_rays,
+                    "rays_entering_tree_rank0": cnt["tree_rays"],
+                    "Mrays_per_s_over_rays_entering_tree_rank0": round(cnt["tree_rays"] / (kern_ms * 1e-3) / 1e6, 1),
+                    "frames_in_flight": nfl,
+                    "rays_per_rank": per_rank,
+                    "gather_ms_max_over_ranks": round(gather_max, 3),
+                    "gather": "this rank's CgrtHit frame device -> pinned host, one async copy (not part of value)",
+                    "bvh_build_and_upload_s": round(setup_s, 3),
+                    "scene_device_MB": round(scene.device_bytes() / 1e6, 1),
+                    "timing": "value and ms_per_step: wall clock between barriers (max over ranks) / steps; roofline.kernel_ms: HIP events on the launch stream (rank 0)",
+                },
+                "roofline": {
+                    "bound": "hbm",
+                    "bound_note": "classification of SURVEY.md 8(d); the profiles show the kernel latency/issue-bound: physical HBM traffic is a few % of the "
+                                  "algorithmic bytes (records are re-read through L1/L2/Infinity Cache) -- see hbm_physical_frac",
+                    "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "hbm_physical_frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "kernel": "k_trace_primary",
+                    "kernel_ms": round(kern_ms, 4),
+                    "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "algorithmic_bytes_per_ray_entering_tree": round((alg_bytes - cnt["rays"] * rs["hit"]) / tree + rs["hit"], 1),
+                    "per_ray": {k: round(cnt[k] / max(1, cnt["rays"]), 3) for k in ("inner_visits", "leaf_visits", "tri_tests", "sub_visits", "cert_boxes")},
+                    "per_ray_entering_tree": {k: round(cnt[k] / tree, 2) for k in ("inner_visits", "tri_tests", "sub_visits", "cert_boxes")},
+                    "fallback_rays": cnt["fallback_rays"],
+                },
+            }
+            if world > 1:
+                out["scaling"] = scaling
+                if n1_same is not None:
+                    out["config"]["n1_same_frame_Mrays_per_s"] = round(n1_same, 1)
+                    out["config"]["n1_same_frame_note"] = "rank 0 alone on the whole frame, after the timed region: the base of this curve"
+    else:  # shaded: the reference's whole frame (renderRayTracing, main.cpp:648-720) on the device wavefront, depth 2
+        if world > 1:
+            raise SystemExit("--workload shaded is a single-GPU line")
+        best = None
+        for _ in range(args.warmup):
+            scene.render(cam, W, H, max_level=2)
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            _, st = scene.render(cam, W, H, max_level=2)
+            if best is None or st["device_ms"] < best["device_ms"]:
+                best = st
+        wall = time.perf_counter() - t_start
+        rays = best["primary_rays"] + best["shadow_rays"] + best["reflection_rays"]
         out = {
-            "metric": "primary Mrays/sec (BVH traversal + ray-triangle, dragon stand-in @1920x1080 per GPU)",
-            "value": round(total_rays / (wall_max / args.steps) / 1e6, 3),
+            "metric": f"rays/sec of the whole shaded frame (primary + shadow + mirror, depth 2, {scene_name} @{W}x{H})",
+            "value": round(rays / (best["device_ms"] * 1e-3) / 1e6, 3),
             "unit": "Mrays/s",
-            "n_gpus": world,
+            "n_gpus": 1,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step": round(best["device_ms"], 4),
             "higher_is_better": True,
-            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (procedural dragon stand-in: data/dragon.obj is absent from the reference checkout)",
-            "config": {
-                "workload": f"dragon stand-in {sd.ntris} tris (1 mesh, 12-level reference BVH), {W}x{H} primary rays, "
-                            f"reference default camera, 8x8 tiles interleaved over {world} rank(s)",
-                "rays_per_step": total_rays,
-                "frames_in_flight": nfl,
-                "rays_rank0": my_rays,
-                "bvh_build_and_upload_s": round(setup_s, 3),
-                "scene_device_MB": round(scene.device_bytes() / 1e6, 1),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "kernel": "k_trace_primary",
-                "kernel_ms": round(kern_ms, 4),
-                "algorithmic_bytes_per_launch": int(alg_bytes),
-                "per_ray": {k: round(cnt[k] / max(1, cnt["rays"]), 2) for k in ("inner_visits", "leaf_visits", "tri_tests", "sub_visits")},
-            },
+            "data": data,
+            "config": {"workload": f"{scene_name}, {W}x{H}, cgrt_render depth 2 ({walk} walk): {best['primary_rays']} primary, "
+                                   f"{best['shadow_rays']} shadow, {best['reflection_rays']} mirror rays",
+                       "timing": "ms_per_step: HIP events around all kernels of the best frame (device side of cgrt_render); "
+                                 f"host-inclusive mean {wall / args.steps * 1e3:.3f} ms (RGB download included)"},
         }
+    if rank == 0 and out is not None:
+        if world == 1 and args.workload == "primary" and not args.no_extras and scaling == "headline" and not args.obj and not (args.width and args.height):
+            # secondary lines of SURVEY.md section 8(d): the config-5 frame on this one GPU (base of the strong-scaling curve)
+            # and the report's 87 K-triangle dragon beside the 800 K one
+            extras = {}
+            W5, H5 = CONFIG5
+            cam5 = pkg.scenes.default_camera(W5, H5)
+            s5, _, _ = primary_runner(scene, cam5, W5, H5, 0, 1)
+            w5, k5 = timed(s5, max(10, args.steps // 2), 3)
+            extras["config5_frame_on_one_gpu"] = {"frame": f"{W5}x{H5}", "Mrays_per_s": round(W5 * H5 / (w5 / max(10, args.steps // 2)) / 1e6, 1),
+                                                  "kernel_ms": round(k5, 4)}
+            if args.tris != 87_000:
+                sd87 = pkg.scenes.make_dragon(87_000)
+                sc87 = pkg.Scene(sd87, device=local_rank)
+                if args.walk != "auto":
+                    sc87.set_walk(args.walk == "certified")
+                s87, _, _ = primary_runner(sc87, cam, W, H, 0, 1)
+                w87, k87 = timed(s87, max(10, args.steps // 2), 3)
+                extras["dragon_87k_report_size"] = {"tris": sd87.ntris, "frame": f"{W}x{H}", "Mrays_per_s": round(W * H / (w87 / max(10, args.steps // 2)) / 1e6, 1),
+                                                    "kernel_ms": round(k87, 4)}
+            out["extras"] = extras
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg, sd, cam, W, H, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(sd, cam, W, H, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -58,6 +58,11 @@ class RenderStats(C.Structure):
                 ("device_ms", C.c_float), ("soft_shadow_rays", C.c_uint64)]
 
 
+class MultiStats(C.Structure):
+    _fields_ = [("replicas", C.c_int32), ("kernel_ms_max", C.c_float), ("download_ms_max", C.c_float), ("wall_ms", C.c_double),
+                ("rays", C.c_uint64 * 64)]
+
+
 class SoftShadows(C.Structure):
     _fields_ = [("spherical", C.c_void_p), ("unit_vectors", C.c_void_p), ("nspherical", C.c_uint32), ("samples", C.c_uint32),
                 ("nunits", C.c_uint32), ("seed", C.c_uint32), ("closest_hit", C.c_int32)]
@@ -102,8 +107,8 @@ _lib: Optional[C.CDLL] = None
 # every symbol include/cgrt.h declares
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
-    "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
+    "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
 ]  # fmt: skip
@@ -143,6 +148,7 @@ def lib() -> C.CDLL:
     L.cgrt_device_bytes.argtypes = [vp]
     L.cgrt_device_bytes.restype = u64
     L.cgrt_intersect_batch.argtypes = [vp, vp, u64, vp, vp]
+    L.cgrt_intersect_brute_batch.argtypes = [vp, vp, u64, i32, vp, vp]
     L.cgrt_intersect_batch_device.argtypes = [vp, vp, u64, vp, vp, vp]
     L.cgrt_trace_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp]
     L.cgrt_trace_primary_device.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp, vp]
@@ -150,6 +156,8 @@ def lib() -> C.CDLL:
     L.cgrt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats)]
     L.cgrt_render_soft.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, vp, C.POINTER(RenderStats)]
     L.cgrt_render_rank.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, i32, i32, vp, C.POINTER(RenderStats)]
+    L.cgrt_trace_primary_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(Camera), i32, i32, vp, vp, C.POINTER(MultiStats)]
+    L.cgrt_render_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, vp, C.POINTER(RenderStats)]
     L.cgrt_count_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [C.POINTER(Counters)]
     L.cgrt_count_batch.argtypes = [vp, vp, u64, C.POINTER(Counters)]
     L.cgrt_debug_gather_calibration.argtypes = [i32, u64, i32]
@@ -306,6 +314,14 @@ class Scene:
         _check(lib().cgrt_intersect_batch(self._h, _ptr(rays), len(rays), _ptr(hits), _ptr(normals)))
         return hits, normals
 
+    def intersect_brute(self, rays: np.ndarray, mesh: int = -1, want_normals: bool = True):
+        """cgrt_intersect_brute_batch: every triangle, no tree (ray_tracing.cpp:202-213). mesh < 0: all meshes + spheres."""
+        rays = _as_ray_array(rays)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        normals = np.zeros((len(rays), 3), np.float32) if want_normals else None
+        _check(lib().cgrt_intersect_brute_batch(self._h, _ptr(rays), len(rays), mesh, _ptr(hits), _ptr(normals)))
+        return hits, normals
+
     def trace_primary(self, cam, W: int, H: int, rect=None, rank: int = 0, nranks: int = 1, want_normals: bool = False):
         x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
         hits = np.zeros(W * H, HIT_DTYPE)
@@ -407,6 +423,34 @@ class Scene:
         return out.as_dict()
 
 
+# ---- one caller, N devices, one framebuffer ----
+def trace_primary_multi(scenes, cam, W: int, H: int, want_normals: bool = False):
+    """cgrt_trace_primary_multi over replicas `scenes` (one Scene per device / rank). Returns (hits, normals or None, stats dict)."""
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    hits = np.zeros(W * H, HIT_DTYPE)
+    normals = np.zeros((W * H, 3), np.float32) if want_normals else None
+    st = MultiStats()
+    c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+    _check(lib().cgrt_trace_primary_multi(arr, len(scenes), C.byref(c), W, H, _ptr(hits), _ptr(normals), C.byref(st)))
+    return hits, normals, dict(replicas=st.replicas, kernel_ms_max=st.kernel_ms_max, download_ms_max=st.download_ms_max, wall_ms=st.wall_ms,
+                               rays=[int(st.rays[i]) for i in range(len(scenes))])
+
+
+def render_multi(scenes, cam, W: int, H: int, lights=None, max_level: int = 2, spherical=None, units=None, samples: int = 200, seed: int = 0):
+    """cgrt_render_multi over replicas `scenes`. Returns (rgb[W*H,3], stats dict)."""
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    lights = _f32(scenes[0].sd.point_lights if lights is None else lights, (-1, 6))
+    rgb = np.zeros((W * H, 3), np.float32)
+    st = RenderStats()
+    q = None
+    if spherical is not None:
+        spherical, units = _f32(spherical, (-1, 7)), _f32(units, (-1, 3))
+        q = C.byref(SoftShadows(spherical.ctypes.data, units.ctypes.data, len(spherical), samples, len(units), seed, 0))
+    c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+    _check(lib().cgrt_render_multi(arr, len(scenes), C.byref(c), W, H, _ptr(lights), len(lights), q, max_level, _ptr(rgb), C.byref(st)))
+    return rgb, {k: getattr(st, k) for k, _ in st._fields_}
+
+
 # ---- element-wise primitives (src/ray_tracing.h:10-20) ----
 def ray_triangle(tri18, rays, device=0):
     tri18 = _f32(tri18, (-1, 18))
@@ -486,6 +530,8 @@ def host_lib() -> C.CDLL:
         H.cgrt_host_load_obj.argtypes = [C.c_char_p, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp]
         H.cgrt_host_write_bmp.argtypes = [C.c_char_p, vp, i32, i32]
         H.cgrt_host_selftest.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, C.POINTER(i32)]
+        H.cgrt_host_threads_test.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, i32, vp]
+        H.cgrt_host_render_bmp.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, i32, C.c_char_p, vp]
         _host = H
     return _host
 
@@ -553,6 +599,34 @@ def host_selftest(sd: SceneData, rays7) -> Tuple[int, int]:
     if bad < 0:
         raise RuntimeError("cgrt_host_selftest: " + Hl.cgrt_host_last_error().decode())
     return int(bad), int(lv.value)
+
+
+def host_threads_test(sd: SceneData, rays7, nthreads: int = 8):
+    """nthreads std::threads call BoundingVolumeHierarchy::intersect per ray on ONE BVH object (as main.cpp:653-656 does);
+    returns (disagreements with intersectBatch, timing dict)."""
+    Hl = host_lib()
+    pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+    tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
+    r = _f32(rays7, (-1, 7))
+    tim = np.zeros(3, np.float64)
+    bad = Hl.cgrt_host_threads_test(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(r), len(r), nthreads, _ptr(tim))
+    if bad < 0:
+        raise RuntimeError("cgrt_host_threads_test: " + Hl.cgrt_host_last_error().decode())
+    return int(bad), dict(us_per_call_one_thread=float(tim[0]), us_per_call_per_thread=float(tim[1]), calls_per_second=float(tim[2]))
+
+
+def host_render_bmp(sd: SceneData, cam, W: int, H: int, path: str, max_level: int = 2, nreplicas: int = 1):
+    """Scene -> device render (nreplicas BVH replicas sharing the frame) -> Screen -> BMP file; returns the float frame (W*H, 3)."""
+    Hl = host_lib()
+    pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+    tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
+    lights, camv = _f32(sd.point_lights, (-1, 6)), _f32(cam, (9,))
+    rgb = np.zeros((W * H, 3), np.float32)
+    rc = Hl.cgrt_host_render_bmp(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(lights), len(lights), _ptr(camv),
+                                 W, H, max_level, nreplicas, path.encode(), _ptr(rgb))
+    if rc:
+        raise RuntimeError("cgrt_host_render_bmp: " + Hl.cgrt_host_last_error().decode())
+    return rgb
 
 
 def host_write_bmp(path: str, rgb, W: int, H: int) -> None:

@@ -4,7 +4,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -27,8 +31,11 @@ static_assert(sizeof(CgrtHit) == sizeof(CgrtHitDev), "CgrtHit layout");
 namespace {
 
 thread_local std::string g_err;
-BuildOptions g_build_options;  // process-wide, set through cgrt_set_leaf_accel before cgrt_scene_create
-int g_primary_mode = 0;        // cgrt_set_primary_mode: 0 = one wave per tile, 1 = persistent waves with lane refill
+// Process-wide options (cgrt_set_leaf_accel / cgrt_set_fast_tree / cgrt_set_primary_mode).  The build options are copied
+// under a mutex when a scene is created; the primary mode is read atomically by every launch.
+std::mutex g_options_mutex;
+BuildOptions g_build_options;
+std::atomic<int> g_primary_mode{0};  // 0 = one wave per tile, 1 = persistent waves with lane refill
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -109,6 +116,7 @@ bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nran
     const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
     F.nst_rank = (uint32_t)((nst + (uint64_t)nranks - 1 - (uint64_t)rank) / (uint64_t)nranks);
     F.nblocks = ((F.nst_rank + 7u) / 8u) * 8u * 16u;
+    F.packed = 0;
     return true;
 }
 
@@ -145,9 +153,23 @@ struct CgrtScene {
     void* d_paths = nullptr;
     uint32_t fast_root = REF_NONE;  // the scene's fast tree (REF_NONE: none); dev.fast_root is this or REF_NONE by cgrt_scene_set_walk
     uint32_t nmesh = 0;
-    unsigned long long* d_counters = nullptr;
-    unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, one per launch in flight
-    unsigned launch_seq = 0;
+    unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, reset by every launch
+    std::atomic<unsigned> launch_seq{0};
+    // Host-pointer entries (cgrt_intersect_batch, cgrt_trace_primary, cgrt_count_*, ...) run on "call lanes": a private
+    // stream + device scratch + pinned staging + a counter block, taken from this pool for the duration of one call and
+    // kept afterwards.  Concurrent callers (the reference calls intersect from an omp parallel for, main.cpp:653-656) get
+    // different lanes; no call allocates, frees or synchronises the device once its lane has grown to the call's size.
+    struct CallLane {
+        hipStream_t stream = nullptr;
+        struct Buf {
+            void* p = nullptr;
+            size_t cap = 0;
+        } dev[3], pin[3];  // rays / hits / normals
+        unsigned long long* d_counters = nullptr;
+    };
+    std::mutex lanes_mutex;
+    std::vector<CallLane*> lanes_free, lanes_all;
+    std::mutex render_mutex;  // cgrt_render* share the workspace below: one frame per scene at a time
     unsigned persistent_blocks = 1024;  // 4 workgroups per CU
     // Device workspace of cgrt_render*: kept between frames (a frame of the same shape then allocates nothing; hipMalloc and
     // hipFree of ~20 buffers cost more than the frame itself), grown on demand, released with the scene.
@@ -159,8 +181,17 @@ struct CgrtScene {
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_counters, (void*)d_queues})
+        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues})
             if (p) (void)hipFree(p);
+        for (CallLane* L : lanes_all) {
+            for (auto& b : L->dev)
+                if (b.p) (void)hipFree(b.p);
+            for (auto& b : L->pin)
+                if (b.p) (void)hipHostFree(b.p);
+            if (L->d_counters) (void)hipFree(L->d_counters);
+            if (L->stream) (void)hipStreamDestroy(L->stream);
+            delete L;
+        }
         for (WorkSlot& w : work)
             if (w.p) (void)hipFree(w.p);
     }
@@ -238,7 +269,11 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
         s->device = device;
         s->ntris = ntris;
         std::string err;
-        BuildOptions bo = g_build_options;
+        BuildOptions bo;
+        {
+            std::lock_guard<std::mutex> lk(g_options_mutex);
+            bo = g_build_options;
+        }
         if (const char* e = getenv("CGRT_FAST_OPEN")) bo.fast_open = atoi(e);  // experiment knob
         if (!build_reference_bvh(hs, bo, s->bvh, err)) {
             delete s;
@@ -277,12 +312,7 @@ int cgrt_scene_create(const float* pos_nrm, uint32_t nverts, const uint32_t* tri
             delete s;
             return rc;
         }
-        hipError_t e = hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long));
-        if (e != hipSuccess) {
-            delete s;
-            return hip_fail(e, "hipMalloc(counters)");
-        }
-        e = hipMalloc((void**)&s->d_queues, 8 * CGRT_QUEUE_BLOCK_WORDS * sizeof(unsigned int));
+        hipError_t e = hipMalloc((void**)&s->d_queues, 8 * CGRT_QUEUE_BLOCK_WORDS * sizeof(unsigned int));
         if (e == hipSuccess) e = hipMemset(s->d_queues, 0, 8 * CGRT_QUEUE_BLOCK_WORDS * sizeof(unsigned int));
         if (e != hipSuccess) {
             delete s;
@@ -331,17 +361,19 @@ void cgrt_scene_destroy(CgrtScene* scene) { delete scene; }
 
 int cgrt_set_leaf_accel(int enabled, int sub_leaf_tris) {
     if (sub_leaf_tris < 0 || sub_leaf_tris > 64) return fail(CGRT_E_ARG, "sub_leaf_tris must be in 0..64 (0 = default)");
+    std::lock_guard<std::mutex> lk(g_options_mutex);
     g_build_options.leaf_accel = enabled != 0;
     g_build_options.sub_leaf_tris = sub_leaf_tris ? sub_leaf_tris : SUB_LEAF_TRIS;
     return CGRT_OK;
 }
 int cgrt_set_primary_mode(int mode) {
     if (mode != 0 && mode != 1) return fail(CGRT_E_ARG, "mode must be 0 (wave per tile) or 1 (persistent waves, lane refill)");
-    g_primary_mode = mode;
+    g_primary_mode.store(mode);
     return CGRT_OK;
 }
 int cgrt_set_fast_tree(int mode) {
     if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (scenes with fat leaves), 0 (never) or 1 (whenever possible)");
+    std::lock_guard<std::mutex> lk(g_options_mutex);
     g_build_options.fast_tree = mode;
     return CGRT_OK;
 }
@@ -500,6 +532,104 @@ void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_
 #define NEED_DEVICE(s) \
     if ((s)->device < 0) return fail(CGRT_E_NO_DEVICE, "scene was created host-only (CGRT_DEVICE_NONE); there is no CPU traversal path")
 
+// A call lane of the scene for the duration of one host-pointer call (RAII).
+namespace {
+struct LaneGuard {
+    CgrtScene* sc;
+    CgrtScene::CallLane* L = nullptr;
+    explicit LaneGuard(CgrtScene* s) : sc(s) {}
+    ~LaneGuard() {
+        if (!L) return;
+        std::lock_guard<std::mutex> lk(sc->lanes_mutex);
+        sc->lanes_free.push_back(L);
+    }
+    int acquire() {
+        {
+            std::lock_guard<std::mutex> lk(sc->lanes_mutex);
+            if (!sc->lanes_free.empty()) {
+                L = sc->lanes_free.back();
+                sc->lanes_free.pop_back();
+                return CGRT_OK;
+            }
+        }
+        CgrtScene::CallLane* n = new (std::nothrow) CgrtScene::CallLane();
+        if (!n) return fail(CGRT_E_ALLOC, "host allocation failed");
+        hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void**)&n->d_counters, 8 * sizeof(unsigned long long));
+        if (e != hipSuccess) {
+            if (n->stream) (void)hipStreamDestroy(n->stream);
+            delete n;
+            return hip_fail(e, "creating a call lane");
+        }
+        {
+            std::lock_guard<std::mutex> lk(sc->lanes_mutex);
+            sc->lanes_all.push_back(n);
+        }
+        L = n;
+        return CGRT_OK;
+    }
+    // scratch that only grows (geometrically): k = 0 rays, 1 hits, 2 normals
+    hipError_t dev(int k, size_t bytes, void** out) {
+        auto& b = L->dev[k];
+        if (b.cap < bytes) {
+            if (b.p) (void)hipFree(b.p);
+            b.p = nullptr;
+            b.cap = 0;
+            const size_t want = std::max<size_t>(bytes, 4096) * 3 / 2;
+            const hipError_t e = hipMalloc(&b.p, want);
+            if (e != hipSuccess) return e;
+            b.cap = want;
+        }
+        *out = b.p;
+        return hipSuccess;
+    }
+    hipError_t pin(int k, size_t bytes, void** out) {
+        auto& b = L->pin[k];
+        if (b.cap < bytes) {
+            if (b.p) (void)hipHostFree(b.p);
+            b.p = nullptr;
+            b.cap = 0;
+            const size_t want = std::max<size_t>(bytes, 4096) * 3 / 2;
+            const hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            b.cap = want;
+        }
+        *out = b.p;
+        return hipSuccess;
+    }
+};
+// Transfers below this size go through the lane's pinned staging buffers (a pageable hipMemcpyAsync of a few bytes costs
+// far more than copying them twice); larger ones are handed to the runtime directly.
+const size_t kStageBytes = 1u << 20;
+
+// host -> device on the lane's stream; `stage` = the pinned buffer to bounce through for small transfers
+hipError_t lane_upload(LaneGuard& g, int k, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes <= kStageBytes) {
+        void* st = nullptr;
+        const hipError_t e = g.pin(k, bytes, &st);
+        if (e != hipSuccess) return e;
+        std::memcpy(st, src, bytes);
+        return hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, g.L->stream);
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g.L->stream);
+}
+// device -> host: returns the pinned address to copy from after the stream has been synchronised (nullptr: the copy went
+// straight into dst)
+hipError_t lane_download(LaneGuard& g, int k, void* dst, const void* src, size_t bytes, void** staged) {
+    *staged = nullptr;
+    if (bytes == 0) return hipSuccess;
+    if (bytes <= kStageBytes) {
+        void* st = nullptr;
+        const hipError_t e = g.pin(k, bytes, &st);
+        if (e != hipSuccess) return e;
+        *staged = st;
+        return hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, g.L->stream);
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g.L->stream);
+}
+}  // namespace
+
 int cgrt_intersect_batch_device(CgrtScene* s, const CgrtRay* d_rays, uint64_t n, CgrtHit* d_hits, float* d_normals, void* stream) {
     if (!s || (n && (!d_rays || !d_hits))) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
@@ -514,20 +644,64 @@ int cgrt_intersect_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtHit*
     NEED_DEVICE(s);
     if (n == 0) return CGRT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    DevBuf dr, dh, dn;
-    HIP_TRY(dr.alloc(n * sizeof(CgrtRay)));
-    HIP_TRY(dh.alloc(n * sizeof(CgrtHit)));
-    HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(CgrtRay), hipMemcpyHostToDevice));
-    if (normals) {
-        HIP_TRY(dn.alloc(n * 12));
-        // HitInfo is left untouched on a miss: start from the caller's contents
-        HIP_TRY(hipMemcpy(dn.p, normals, n * 12, hipMemcpyHostToDevice));
-    }
-    int rc = cgrt_intersect_batch_device(s, dr.as<CgrtRay>(), n, dh.as<CgrtHit>(), normals ? dn.as<float>() : nullptr, nullptr);
+    LaneGuard g(s);
+    int rc = g.acquire();
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(CgrtHit), hipMemcpyDeviceToHost));
-    if (normals) HIP_TRY(hipMemcpy(normals, dn.p, n * 12, hipMemcpyDeviceToHost));
+    void *dr, *dh, *dn = nullptr;
+    HIP_TRY(g.dev(0, n * sizeof(CgrtRay), &dr));
+    HIP_TRY(g.dev(1, n * sizeof(CgrtHit), &dh));
+    HIP_TRY(lane_upload(g, 0, dr, rays, n * sizeof(CgrtRay)));
+    if (normals) {
+        HIP_TRY(g.dev(2, n * 12, &dn));
+        HIP_TRY(lane_upload(g, 2, dn, normals, n * 12));  // HitInfo is left untouched on a miss: start from the caller's contents
+    }
+    rc = cgrt_intersect_batch_device(s, static_cast<const CgrtRay*>(dr), n, static_cast<CgrtHit*>(dh), static_cast<float*>(dn), g.L->stream);
+    if (rc) return rc;
+    void *sh = nullptr, *sn = nullptr;
+    HIP_TRY(lane_download(g, 1, hits, dh, n * sizeof(CgrtHit), &sh));
+    if (normals) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn));
+    HIP_TRY(hipStreamSynchronize(g.L->stream));  // this call's stream only: other streams and threads are not stalled
+    if (sh) std::memcpy(hits, sh, n * sizeof(CgrtHit));
+    if (sn) std::memcpy(normals, sn, n * 12);
+    return CGRT_OK;
+}
+
+int cgrt_intersect_brute_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, int mesh, CgrtHit* hits, float* normals) {
+    if (!s || (n && (!rays || !hits))) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    if (mesh >= (int)s->nmesh) return fail(CGRT_E_ARG, "mesh index out of range");
+    if (n == 0) return CGRT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    LaneGuard g(s);
+    int rc = g.acquire();
+    if (rc) return rc;
+    void *dr, *dh, *dn = nullptr;
+    HIP_TRY(g.dev(0, n * sizeof(CgrtRay), &dr));
+    HIP_TRY(g.dev(1, n * sizeof(CgrtHit), &dh));
+    HIP_TRY(lane_upload(g, 0, dr, rays, n * sizeof(CgrtRay)));
+    if (normals) {
+        HIP_TRY(g.dev(2, n * 12, &dn));
+        HIP_TRY(lane_upload(g, 2, dn, normals, n * 12));
+    }
+    HIP_TRY(launch_brute_batch(s->dev, static_cast<const float*>(dr), n, mesh < 0 ? -1 : mesh, static_cast<CgrtHitDev*>(dh), static_cast<float*>(dn),
+                               g.L->stream));
+    void *sh = nullptr, *sn = nullptr;
+    HIP_TRY(lane_download(g, 1, hits, dh, n * sizeof(CgrtHit), &sh));
+    if (normals) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn));
+    HIP_TRY(hipStreamSynchronize(g.L->stream));
+    if (sh) std::memcpy(hits, sh, n * sizeof(CgrtHit));
+    if (sn) std::memcpy(normals, sn, n * 12);
+    return CGRT_OK;
+}
+
+static int launch_primary(CgrtScene* s, const CameraDev& C, const FrameDev& F, CgrtHitDev* d_hits, float* d_normals, unsigned long long* counters,
+                          hipStream_t stream) {
+    if (g_primary_mode.load() == 1) {
+        unsigned int* q = s->d_queues + CGRT_QUEUE_BLOCK_WORDS * (s->launch_seq.fetch_add(1) & 7u);
+        HIP_TRY(launch_trace_primary_persistent(s->dev, C, F, d_hits, d_normals, counters, q, s->persistent_blocks, stream));
+    } else {
+        HIP_TRY(launch_trace_primary(s->dev, C, F, d_hits, d_normals, counters, stream));
+    }
     return CGRT_OK;
 }
 
@@ -538,15 +712,7 @@ int cgrt_trace_primary_device(CgrtScene* s, const CgrtCamera* cam, int W, int H,
     FrameDev F;
     if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
     HIP_TRY(hipSetDevice(s->device));
-    if (g_primary_mode == 1) {
-        unsigned int* q = s->d_queues + CGRT_QUEUE_BLOCK_WORDS * (s->launch_seq++ & 7u);
-        HIP_TRY(launch_trace_primary_persistent(s->dev, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr, q,
-                                                s->persistent_blocks, static_cast<hipStream_t>(stream)));
-    } else {
-        HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr,
-                                     static_cast<hipStream_t>(stream)));
-    }
-    return CGRT_OK;
+    return launch_primary(s, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int cgrt_trace_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1, int rank, int nranks,
@@ -556,19 +722,24 @@ int cgrt_trace_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     if (W <= 0 || H <= 0) return fail(CGRT_E_ARG, "bad frame size");
     HIP_TRY(hipSetDevice(s->device));
     const size_t npix = (size_t)W * (size_t)H;
-    DevBuf dh, dn;
-    HIP_TRY(dh.alloc(npix * sizeof(CgrtHit)));
-    HIP_TRY(hipMemcpy(dh.p, hits, npix * sizeof(CgrtHit), hipMemcpyHostToDevice));  // pixels outside the tiles keep caller data
-    if (normals) {
-        HIP_TRY(dn.alloc(npix * 12));
-        HIP_TRY(hipMemcpy(dn.p, normals, npix * 12, hipMemcpyHostToDevice));
-    }
-    int rc = cgrt_trace_primary_device(s, cam, W, H, x0, y0, x1, y1, rank, nranks, dh.as<CgrtHit>(), normals ? dn.as<float>() : nullptr,
-                                       nullptr);
+    LaneGuard g(s);
+    int rc = g.acquire();
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(hits, dh.p, npix * sizeof(CgrtHit), hipMemcpyDeviceToHost));
-    if (normals) HIP_TRY(hipMemcpy(normals, dn.p, npix * 12, hipMemcpyDeviceToHost));
+    void *dh, *dn = nullptr;
+    HIP_TRY(g.dev(1, npix * sizeof(CgrtHit), &dh));
+    HIP_TRY(lane_upload(g, 1, dh, hits, npix * sizeof(CgrtHit)));  // pixels outside the tiles keep caller data
+    if (normals) {
+        HIP_TRY(g.dev(2, npix * 12, &dn));
+        HIP_TRY(lane_upload(g, 2, dn, normals, npix * 12));
+    }
+    rc = cgrt_trace_primary_device(s, cam, W, H, x0, y0, x1, y1, rank, nranks, static_cast<CgrtHit*>(dh), static_cast<float*>(dn), g.L->stream);
+    if (rc) return rc;
+    void *sh = nullptr, *sn = nullptr;
+    HIP_TRY(lane_download(g, 1, hits, dh, npix * sizeof(CgrtHit), &sh));
+    if (normals) HIP_TRY(lane_download(g, 2, normals, dn, npix * 12, &sn));
+    HIP_TRY(hipStreamSynchronize(g.L->stream));
+    if (sh) std::memcpy(hits, sh, npix * sizeof(CgrtHit));
+    if (sn) std::memcpy(normals, sn, npix * 12);
     return CGRT_OK;
 }
 
@@ -580,18 +751,23 @@ int cgrt_generate_rays(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = (size_t)(x1 - x0) * (size_t)(y1 - y0);
     if (!n) return CGRT_OK;
-    DevBuf dr;
-    HIP_TRY(dr.alloc(n * sizeof(CgrtRay)));
-    HIP_TRY(launch_generate_rays(make_camera(*cam), W, H, x0, y0, x1, y1, dr.as<float>(), nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(rays, dr.p, n * sizeof(CgrtRay), hipMemcpyDeviceToHost));
+    LaneGuard g(s);
+    int rc = g.acquire();
+    if (rc) return rc;
+    void* dr;
+    HIP_TRY(g.dev(0, n * sizeof(CgrtRay), &dr));
+    HIP_TRY(launch_generate_rays(make_camera(*cam), W, H, x0, y0, x1, y1, static_cast<float*>(dr), g.L->stream));
+    void* sr = nullptr;
+    HIP_TRY(lane_download(g, 0, rays, dr, n * sizeof(CgrtRay), &sr));
+    HIP_TRY(hipStreamSynchronize(g.L->stream));
+    if (sr) std::memcpy(rays, sr, n * sizeof(CgrtRay));
     return CGRT_OK;
 }
 
-static int read_counters(CgrtScene* s, CgrtCounters* out) {
+static int read_counters(LaneGuard& g, CgrtCounters* out) {
     unsigned long long h[8];
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(h, g.L->d_counters, sizeof(h), hipMemcpyDeviceToHost, g.L->stream));
+    HIP_TRY(hipStreamSynchronize(g.L->stream));
     out->rays = h[0];
     out->inner_visits = h[1];
     out->leaf_visits = h[2];
@@ -610,17 +786,15 @@ int cgrt_count_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     FrameDev F;
     if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
     HIP_TRY(hipSetDevice(s->device));
-    DevBuf dh;
-    HIP_TRY(dh.alloc((size_t)W * (size_t)H * sizeof(CgrtHit)));
-    HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
-    if (g_primary_mode == 1) {
-        unsigned int* q = s->d_queues + CGRT_QUEUE_BLOCK_WORDS * (s->launch_seq++ & 7u);
-        HIP_TRY(launch_trace_primary_persistent(s->dev, make_camera(*cam), F, dh.as<CgrtHitDev>(), nullptr, s->d_counters, q,
-                                                s->persistent_blocks, nullptr));
-    } else {
-        HIP_TRY(launch_trace_primary(s->dev, make_camera(*cam), F, dh.as<CgrtHitDev>(), nullptr, s->d_counters, nullptr));
-    }
-    return read_counters(s, out);
+    LaneGuard g(s);
+    int rc = g.acquire();
+    if (rc) return rc;
+    void* dh;
+    HIP_TRY(g.dev(1, (size_t)W * (size_t)H * sizeof(CgrtHit), &dh));
+    HIP_TRY(hipMemsetAsync(g.L->d_counters, 0, 8 * sizeof(unsigned long long), g.L->stream));
+    rc = launch_primary(s, make_camera(*cam), F, static_cast<CgrtHitDev*>(dh), nullptr, g.L->d_counters, g.L->stream);
+    if (rc) return rc;
+    return read_counters(g, out);
 }
 
 int cgrt_debug_wave_times(CgrtScene* s, const CgrtCamera* cam, int W, int H, uint64_t* out, uint64_t cap_waves) {
@@ -646,13 +820,16 @@ int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters
     if (!s || !out || (n && !rays)) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     HIP_TRY(hipSetDevice(s->device));
-    DevBuf dr, dh;
-    HIP_TRY(dr.alloc(n * sizeof(CgrtRay)));
-    HIP_TRY(dh.alloc(n * sizeof(CgrtHit)));
-    if (n) HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(CgrtRay), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
-    HIP_TRY(launch_trace_batch(s->dev, dr.as<float>(), n, dh.as<CgrtHitDev>(), nullptr, s->d_counters, nullptr));
-    return read_counters(s, out);
+    LaneGuard g(s);
+    int rc = g.acquire();
+    if (rc) return rc;
+    void *dr, *dh;
+    HIP_TRY(g.dev(0, n * sizeof(CgrtRay), &dr));
+    HIP_TRY(g.dev(1, n * sizeof(CgrtHit), &dh));
+    HIP_TRY(lane_upload(g, 0, dr, rays, n * sizeof(CgrtRay)));
+    HIP_TRY(hipMemsetAsync(g.L->d_counters, 0, 8 * sizeof(unsigned long long), g.L->stream));
+    HIP_TRY(launch_trace_batch(s->dev, static_cast<const float*>(dr), n, static_cast<CgrtHitDev*>(dh), nullptr, g.L->d_counters, g.L->stream));
+    return read_counters(g, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,6 +846,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         if ((unsigned long long)W * H > 0x7fffffffull) return fail(CGRT_E_ARG, "frame too large");
     }
     HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> one_frame(s->render_mutex);  // the workspace below belongs to one frame at a time
     const unsigned long long npix = (unsigned long long)W * H;
     const unsigned L = nlights;
     CgrtRenderStats st{};
@@ -716,20 +894,21 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     const CameraDev C = make_camera(*cam);
     struct Aux {  // second stream + the events that order it against the default stream
         hipStream_t s = nullptr;
-        hipEvent_t spawned = nullptr, traced = nullptr;
+        hipEvent_t spawned = nullptr, traced = nullptr, e0 = nullptr, e1 = nullptr;
         ~Aux() {
             if (spawned) (void)hipEventDestroy(spawned);
             if (traced) (void)hipEventDestroy(traced);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
             if (s) (void)hipStreamDestroy(s);
         }
     } aux;
     HIP_TRY(hipStreamCreateWithFlags(&aux.s, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&aux.spawned, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&aux.traced, hipEventDisableTiming));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, nullptr));
+    HIP_TRY(hipEventCreate(&aux.e0));
+    HIP_TRY(hipEventCreate(&aux.e1));
+    HIP_TRY(hipEventRecord(aux.e0, nullptr));
     int nlev = 0;
     std::vector<unsigned long long> level_count;  // entries per evaluated level
     HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
@@ -799,12 +978,10 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
         HIP_TRY(launch_write_rgb(levels.as<float>(), level_count[0], ipix.as<int>(), drgb.as<float>(), nullptr));
     }
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(aux.e1, nullptr));
+    HIP_TRY(hipEventSynchronize(aux.e1));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(&ms, aux.e0, aux.e1));
     st.device_ms = ms;
     st.levels = nlev;
     HIP_TRY(hipMemcpy(rgb, drgb.p, npix * 12, hipMemcpyDeviceToHost));
@@ -823,6 +1000,189 @@ int cgrt_render_soft(CgrtScene* s, const CgrtCamera* cam, int W, int H, const fl
 int cgrt_render_rank(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
                      int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats) {
     return render_impl(s, cam, W, H, lights, nlights, soft, max_level, rank, nranks, rgb, stats);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One caller, N devices, one framebuffer (main.cpp:648-720 yields ONE Screen).  scenes[i] is a
+// replica of the scene on its own device (the same device may appear several times); replica i traces the super-tiles
+// i % nscenes.  All launches are issued first, each on a private stream of its replica; every device then downloads its
+// pixels with ONE asynchronous copy (the kernel writes them back to back, FrameDev::packed) and a host thread per replica
+// scatters them into the caller's frame.
+namespace {
+// pixel of lane (r, c) = row r, column c of the 8x8 tile of wave w of workgroup b: the host mirror of tile_pixel_of()
+inline bool tile_origin(const FrameDev& F, uint32_t b, uint32_t w, int& x, int& y) {
+    const uint32_t lane8 = b & 7u, j = b >> 3;
+    const uint32_t sl = (j >> 4) * 8u + lane8;
+    if (sl >= F.nst_rank) return false;
+    const uint32_t st = (uint32_t)F.rank + (uint32_t)F.nranks * sl;
+    const int stx = (int)(st % (uint32_t)F.st_x), sty = (int)(st / (uint32_t)F.st_x);
+    const int idx = (int)(j & 15u) * 4 + (int)w;
+    x = F.x0 + (stx * ST_TILES + (idx & 7)) * 8;
+    y = F.y0 + (sty * ST_TILES + (idx >> 3)) * 8;
+    return x < F.x1 && y < F.y1;
+}
+}  // namespace
+
+int cgrt_trace_primary_multi(CgrtScene* const* scenes, int nscenes, const CgrtCamera* cam, int W, int H, CgrtHit* hits, float* normals,
+                             CgrtMultiStats* stats) {
+    if (!scenes || nscenes <= 0 || nscenes > 64 || !cam || !hits) return fail(CGRT_E_ARG, "NULL argument or bad replica count");
+    for (int i = 0; i < nscenes; i++) {
+        if (!scenes[i]) return fail(CGRT_E_ARG, "NULL scene");
+        NEED_DEVICE(scenes[i]);
+        for (int k = 0; k < i; k++)
+            if (scenes[k] == scenes[i]) return fail(CGRT_E_ARG, "the same replica twice: create one scene per rank (the same device may repeat)");
+    }
+    if (W <= 0 || H <= 0) return fail(CGRT_E_ARG, "bad frame size");
+    const CameraDev C = make_camera(*cam);
+    struct Part {
+        FrameDev F;
+        LaneGuard* g = nullptr;
+        void *dh = nullptr, *dn = nullptr, *ph = nullptr, *pn = nullptr;
+        size_t n = 0;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        ~Part() {
+            for (hipEvent_t e : {e0, e1, e2})
+                if (e) (void)hipEventDestroy(e);
+            delete g;
+        }
+    };
+    std::vector<Part> part(nscenes);
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (int i = 0; i < nscenes; i++) {  // issue everything, wait for nothing
+        Part& P = part[i];
+        if (!make_frame(W, H, 0, 0, W, H, i, nscenes, P.F)) return fail(CGRT_E_ARG, "bad frame");
+        P.F.packed = 1;
+        P.n = (size_t)P.F.nblocks * 256u;
+        if (P.n == 0) continue;
+        HIP_TRY(hipSetDevice(scenes[i]->device));
+        P.g = new LaneGuard(scenes[i]);
+        int rc = P.g->acquire();
+        if (rc) return rc;
+        HIP_TRY(P.g->dev(1, P.n * sizeof(CgrtHit), &P.dh));
+        HIP_TRY(P.g->pin(1, P.n * sizeof(CgrtHit), &P.ph));
+        if (normals) {
+            HIP_TRY(P.g->dev(2, P.n * 12, &P.dn));
+            HIP_TRY(P.g->pin(2, P.n * 12, &P.pn));
+        }
+        HIP_TRY(hipEventCreate(&P.e0));
+        HIP_TRY(hipEventCreate(&P.e1));
+        HIP_TRY(hipEventCreate(&P.e2));
+        hipStream_t st = P.g->L->stream;
+        HIP_TRY(hipEventRecord(P.e0, st));
+        HIP_TRY(launch_trace_primary(scenes[i]->dev, C, P.F, static_cast<CgrtHitDev*>(P.dh), static_cast<float*>(P.dn), nullptr, st));
+        HIP_TRY(hipEventRecord(P.e1, st));
+        HIP_TRY(hipMemcpyAsync(P.ph, P.dh, P.n * sizeof(CgrtHit), hipMemcpyDeviceToHost, st));
+        if (normals) HIP_TRY(hipMemcpyAsync(P.pn, P.dn, P.n * 12, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(P.e2, st));
+    }
+    // one host thread per replica: wait for its stream, scatter its tiles (rows of 8 pixels) into the frame
+    std::vector<int> status(nscenes, CGRT_OK);
+    std::vector<std::string> errs(nscenes);
+    auto finish = [&](int i) {
+        Part& P = part[i];
+        if (P.n == 0) return;
+        if (hipSetDevice(scenes[i]->device) != hipSuccess || hipStreamSynchronize(P.g->L->stream) != hipSuccess) {
+            status[i] = CGRT_E_HIP;
+            errs[i] = "waiting for a replica's stream failed";
+            return;
+        }
+        const CgrtHit* ph = static_cast<const CgrtHit*>(P.ph);
+        const float* pn = static_cast<const float*>(P.pn);
+        for (uint32_t b = 0; b < P.F.nblocks; b++)
+            for (uint32_t w = 0; w < 4; w++) {
+                int x, y;
+                if (!tile_origin(P.F, b, w, x, y)) continue;
+                const int cw = std::min(8, P.F.x1 - x), ch = std::min(8, P.F.y1 - y);
+                const size_t base = (size_t)b * 256u + w * 64u;
+                for (int r = 0; r < ch; r++) {
+                    std::memcpy(hits + (size_t)(y + r) * W + x, ph + base + 8 * r, (size_t)cw * sizeof(CgrtHit));
+                    if (normals) {
+                        // hitInfo.normal is only written for rays that hit (HitInfo stays untouched on a miss)
+                        for (int c = 0; c < cw; c++)
+                            if (ph[base + 8 * r + c].hit) std::memcpy(normals + 3 * ((size_t)(y + r) * W + x + c), pn + 3 * (base + 8 * r + c), 12);
+                    }
+                }
+            }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int i = 1; i < nscenes; i++) pool.emplace_back(finish, i);
+        finish(0);
+        for (std::thread& t : pool) t.join();
+    }
+    for (int i = 0; i < nscenes; i++)
+        if (status[i]) return fail(status[i], errs[i]);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->replicas = nscenes;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        for (int i = 0; i < nscenes; i++) {
+            Part& P = part[i];
+            if (P.n == 0) continue;
+            float k = 0, c = 0;
+            (void)hipSetDevice(scenes[i]->device);
+            if (hipEventElapsedTime(&k, P.e0, P.e1) == hipSuccess) stats->kernel_ms_max = std::max(stats->kernel_ms_max, k);
+            if (hipEventElapsedTime(&c, P.e1, P.e2) == hipSuccess) stats->download_ms_max = std::max(stats->download_ms_max, c);
+            stats->rays[i] = owned_pixels(P.F);
+        }
+    }
+    return CGRT_OK;
+}
+
+int cgrt_render_multi(CgrtScene* const* scenes, int nscenes, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
+                      const CgrtSoftShadows* soft, int max_level, float* rgb, CgrtRenderStats* stats) {
+    if (!scenes || nscenes <= 0 || nscenes > 64 || !cam || !rgb) return fail(CGRT_E_ARG, "NULL argument or bad replica count");
+    for (int i = 0; i < nscenes; i++) {
+        if (!scenes[i]) return fail(CGRT_E_ARG, "NULL scene");
+        for (int k = 0; k < i; k++)
+            if (scenes[k] == scenes[i]) return fail(CGRT_E_ARG, "the same replica twice: create one scene per rank (the same device may repeat)");
+    }
+    if (W <= 0 || H <= 0) return fail(CGRT_E_ARG, "bad frame size");
+    // every replica renders its super-tiles (shading included: a pixel's secondary rays stay on the device that owns it) into a
+    // frame of its own on a host thread of its own; the owned pixels are then merged into the caller's frame
+    const size_t npix = (size_t)W * H;
+    std::vector<std::vector<float>> frame(nscenes);
+    std::vector<CgrtRenderStats> st(nscenes);
+    std::vector<int> status(nscenes, CGRT_OK);
+    std::vector<std::string> errs(nscenes);
+    auto work = [&](int i) {
+        try {
+            frame[i].assign(npix * 3, 0.0f);
+        } catch (const std::bad_alloc&) {
+            status[i] = CGRT_E_ALLOC;
+            errs[i] = "host allocation failed";
+            return;
+        }
+        status[i] = render_impl(scenes[i], cam, W, H, lights, nlights, soft, max_level, i, nscenes, frame[i].data(), &st[i]);
+        if (status[i]) errs[i] = g_err;  // (thread-local: carried over to the caller's thread below)
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int i = 1; i < nscenes; i++) pool.emplace_back(work, i);
+        work(0);
+        for (std::thread& t : pool) t.join();
+    }
+    for (int i = 0; i < nscenes; i++)
+        if (status[i]) return fail(status[i], errs[i]);
+    CgrtRenderStats tot{};
+    for (int i = 0; i < nscenes; i++) {
+        FrameDev F;
+        make_frame(W, H, 0, 0, W, H, i, nscenes, F);
+        const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
+        for (uint64_t k = (uint64_t)i; k < nst; k += (uint64_t)nscenes) {
+            const int sx = (int)(k % (uint64_t)F.st_x) * 64, sy = (int)(k / (uint64_t)F.st_x) * 64;
+            const int w = std::min(64, W - sx), h = std::min(64, H - sy);
+            for (int r = 0; r < h; r++) std::memcpy(rgb + 3 * ((size_t)(sy + r) * W + sx), frame[i].data() + 3 * ((size_t)(sy + r) * W + sx), (size_t)w * 12);
+        }
+        tot.primary_rays += st[i].primary_rays;
+        tot.shadow_rays += st[i].shadow_rays;
+        tot.reflection_rays += st[i].reflection_rays;
+        tot.soft_shadow_rays += st[i].soft_shadow_rays;
+        tot.levels = std::max(tot.levels, st[i].levels);
+        tot.device_ms = std::max(tot.device_ms, st[i].device_ms);
+    }
+    if (stats) *stats = tot;
+    return CGRT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -147,6 +147,8 @@ struct FrameDev {
     int rank, nranks;
     uint32_t nst_rank;     // super-tiles this rank owns
     uint32_t nblocks;      // 256-thread workgroups launched: 16 per super-tile, super-tiles padded to 8
+    int packed;            // 1: results are written at blockIdx * 256 + threadIdx (the rank's pixels back to back, in the kernel's
+                           // own order: one contiguous download per device) instead of at y * W + x
 };
 static const int ST_TILES = 8;  // tiles per super-tile side
 

@@ -118,8 +118,65 @@ __global__ void k_fastdiv_check(const float* __restrict__ a, const float* __rest
     }
 }
 
+// intersectRayWithShape(const Mesh&, Ray&, HitInfo&) (ray_tracing.cpp:202-213): EVERY triangle is tested, no tree -- the
+// reference's ground truth over all triangles, and the discriminator of its BVH's false misses.  mesh < 0:
+// all meshes of the scene in load order followed by the spheres (the pre-BVH body of BoundingVolumeHierarchy::intersect,
+// bvh.cpp:854-868, commented out upstream), hitInfo.material written; mesh >= 0: that mesh only, material not written
+// (:202-213 never touches it), no spheres.  One ray per lane; all lanes walk the record array together (uniform addresses).
+// The records lie in leaf order, the reference scans in load order: the outcome of a sequential scan is the lexicographic
+// minimum of (t, position) among the accepted triangles -- a later equal t fails `t >= ray.t` (:65) -- except that an
+// origin-on-plane acceptance (t = 0 without a guard, :43-47) goes to the LAST position; the position is the primitive id.
+__global__ __launch_bounds__(256) void k_brute_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n, int mesh,
+                                                      CgrtHitDev* __restrict__ hits, float* __restrict__ normals) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    const float* r = rays + 7 * (active ? i : 0);
+    const F3 o = f3(r[0], r[1], r[2]), d = f3(r[3], r[4], r[5]);
+    float t = r[6];
+    LeafScan L;
+    L.best_t = t;
+    L.best_k = -1;
+    L.best_rec = REF_NONE;
+    L.onp_k = -1;
+    L.onp_rec = REF_NONE;
+    for (uint32_t k = 0; k < S.ntris; k++) {
+        const uint32_t rec = S.tri_base + k;
+        const TriRecord* T = S.tris + rec;
+        if (mesh >= 0 && T->mesh_id != (uint32_t)mesh) continue;
+        const float4* q = reinterpret_cast<const float4*>(T);
+        TriEval E = eval_record(q[0], q[1], q[2], q[3], o, d);
+        E.k = (int)T->prim_id;  // scan position of the load-order scan
+        apply_eval(E, rec, L);
+    }
+    uint32_t hit_rec = REF_NONE;
+    if (L.onp_k >= 0) {
+        t = 0.0f;
+        hit_rec = L.onp_rec;
+    } else if (L.best_k >= 0) {
+        t = L.best_t;
+        hit_rec = L.best_rec;
+    }
+    if (!active) return;
+    SceneDev S2 = S;
+    if (mesh >= 0) S2.nspheres = 0;
+    CgrtHitDev h;
+    F3 nn;
+    resolve_hit(S2, o, d, t, hit_rec, normals != nullptr, h, nn);
+    if (mesh >= 0) h.material_id = -1;
+    hits[i] = h;
+    if (normals && h.hit) {
+        normals[3 * i] = nn.x;
+        normals[3 * i + 1] = nn.y;
+        normals[3 * i + 2] = nn.z;
+    }
+}
+
 static inline unsigned grid_for(unsigned long long n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+hipError_t launch_brute_batch(const SceneDev& S, const float* rays, unsigned long long n, int mesh, CgrtHitDev* hits, float* normals, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_brute_batch, dim3(grid_for(n, 256)), dim3(256), 0, s, S, rays, n, mesh, hits, normals);
+    return hipGetLastError();
+}
 hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
                                hipStream_t s) {
     if (nrecords)

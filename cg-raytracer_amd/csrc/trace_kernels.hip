@@ -29,7 +29,7 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
     uint32_t hit_rec = REF_NONE;
     walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
     if (active) {
-        const size_t pix = (size_t)y * F.W + x;
+        const size_t pix = F.packed ? (size_t)blockIdx.x * CGRT_BLOCK + threadIdx.x : (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
     if (COUNT) flush_counters(cnt, active, counters);

@@ -575,10 +575,19 @@ __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, ui
             }
         }
     };
+#ifndef CGRT_EXACT_WAVE_LOOP
+#define CGRT_EXACT_WAVE_LOOP 0  // 1: wave-level loop condition, measured 4 % slower for this walk (profiles/r2_exp_exact_wave_loop.txt)
+#endif
+#if CGRT_EXACT_WAVE_LOOP
+    while (__any(!done)) {  // the loop condition is the wave's; the pieces predicate themselves on the lane's state
+        T(); T(); E(); N(); N(); R(); P();
+    }
+#else
     while (!done) {
         // (sequences with more or fewer pieces per iteration measured slower: profiles/r1_exp_one_loop.txt)
         T(); T(); E(); N(); N(); R(); P();
     }
+#endif
 }
 
 // Spheres (bvh.cpp:878-879), result assembly and the accepted hit's interpolated normal

@@ -27,12 +27,14 @@ bool intersectRayWithShape(const Mesh& mesh, Ray& ray, HitInfo& hitInfo);
 class BoundingVolumeHierarchy {
 public:
     BoundingVolumeHierarchy(Scene* pScene);  // builds on the host, uploads to HIP device 0 (CGRT_DEVICE env overrides)
+    BoundingVolumeHierarchy(Scene* pScene, int device);  // a replica on a given device (renderRayTracingOnDevices)
 
     void debugDraw(int level);  // GL-only upstream (bvh.cpp:469-525): kept as a no-op
     int numLevels() const;
 
-    // Return true if something is hit (bvh.cpp:850-881).  One-ray batch through the GPU path: correct, slow;
-    // batch callers should use intersectBatch / tracePrimary.
+    // Return true if something is hit (bvh.cpp:850-881).  One-ray batch through the GPU path; re-entrant: the reference calls
+    // it on one const object from an omp parallel for (main.cpp:653-656), each call here runs on a private stream of the
+    // library and waits for that stream only.  Batch callers should use intersectBatch / tracePrimary.
     bool intersect(Ray& ray, HitInfo& hitInfo) const;
 
     // ---- batched extensions (no upstream counterpart) ----

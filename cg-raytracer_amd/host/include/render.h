@@ -35,6 +35,13 @@ RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, 
                                    int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
 RenderStats renderRayTracingOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen,
                                      int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
+// One frame on several devices: bvhs[i] is a replica of the scene's BVH on its own device
+// (BoundingVolumeHierarchy(&scene, device)); replica i renders the 64x64 super-tiles i % n, shading included, and the
+// frame is assembled in ONE Screen / buffer, as the reference's renderRayTracing yields one (main.cpp:648-720).
+RenderStats renderToBufferOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs, int W, int H,
+                                    float* rgb, int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
+RenderStats renderRayTracingOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs,
+                                      Screen& screen, int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
 // sampler: required when the scene has spherical lights (nullptr -> SoftShadowSampler::gaussian()).
 RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel = 2,
                              const SoftShadowSampler* sampler = nullptr);

@@ -16,7 +16,9 @@ int host_device() {
 [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string(what) + ": " + cgrt_last_error()); }
 }  // namespace
 
-BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene* pScene) : m_pScene(pScene) {
+BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene* pScene) : BoundingVolumeHierarchy(pScene, host_device()) {}
+
+BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene* pScene, int device) : m_pScene(pScene) {
     // flatten Scene::meshes in load order (global primitive id = prefix over meshes + index in mesh.triangles)
     std::vector<float> pos_nrm, mats, sph;
     std::vector<uint32_t> tri, tri_mesh;
@@ -36,7 +38,7 @@ BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene* pScene) : m_pScene(pScen
     for (const Sphere& s : pScene->spheres) sph.insert(sph.end(), {s.center.x, s.center.y, s.center.z, s.radius, -1.0f});
     CgrtScene* h = nullptr;
     if (cgrt_scene_create(pos_nrm.data(), voff, tri.data(), tri_mesh.data(), (uint32_t)tri_mesh.size(), mats.data(), m, sph.data(),
-                          (uint32_t)pScene->spheres.size(), host_device(), &h) != CGRT_OK)
+                          (uint32_t)pScene->spheres.size(), device, &h) != CGRT_OK)
         fail("cgrt_scene_create");
     m_handle = std::shared_ptr<CgrtScene>(h, cgrt_scene_destroy);
 }

@@ -1,7 +1,10 @@
 // C entry points of the host mirror for the Python test harness (ctypes): build a Scene from flat arrays or from
 // an OBJ file, run the wavefront render driver, dump a loaded scene back to flat arrays.
+#include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 
 #include "render.h"
 
@@ -248,6 +251,98 @@ int cgrt_host_write_bmp(const char* path, const float* rgb, int W, int H) {
                 const float* p = rgb + 3 * ((size_t)y * W + x);
                 screen.setPixel(x, y, cgrt::vec3(p[0], p[1], p[2]));
             }
+        screen.writeBitmapToFile(path);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// The reference calls BoundingVolumeHierarchy::intersect on ONE const object from the threads of an omp parallel for
+// (main.cpp:653-656).  nthreads std::threads do the same here, ray i on thread i % nthreads, one ray per call, and every
+// result is compared bit for bit with intersectBatch on the same rays.  timing (optional, 3 doubles): microseconds per
+// per-ray call on one thread, microseconds per call per thread with nthreads threads, aggregate calls per second.
+// Returns the number of disagreements (0 = pass), -1 on an exception.
+int cgrt_host_threads_test(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
+                           const float* materials, uint32_t nmesh, const float* rays7, uint32_t nrays, int nthreads, double* timing) {
+    try {
+        Scene sc = scene_from_arrays(pos_nrm, nverts, tri, tri_mesh, ntris, materials, nmesh, nullptr, 0);
+        const BoundingVolumeHierarchy bvh(&sc);
+        std::vector<Ray> rays(nrays);
+        for (uint32_t i = 0; i < nrays; i++) {
+            const float* p = rays7 + 7 * i;
+            rays[i].origin = cgrt::vec3(p[0], p[1], p[2]);
+            rays[i].direction = cgrt::vec3(p[3], p[4], p[5]);
+            rays[i].t = p[6];
+        }
+        std::vector<Ray> batch = rays;
+        std::vector<HitInfo> bhi(nrays);
+        std::vector<uint8_t> bhit(nrays);
+        bvh.intersectBatch(batch.data(), bhi.data(), bhit.data(), nrays);
+        using Clk = std::chrono::steady_clock;
+        // one thread, per-ray calls (also warms the library's call lanes)
+        const uint32_t nsingle = nrays < 2000 ? nrays : 2000;
+        const auto s0 = Clk::now();
+        for (uint32_t i = 0; i < nsingle; i++) {
+            Ray r = rays[i];
+            HitInfo hi;
+            (void)bvh.intersect(r, hi);
+        }
+        const double single_us = std::chrono::duration<double, std::micro>(Clk::now() - s0).count() / (nsingle ? nsingle : 1);
+        std::vector<Ray> tr = rays;
+        std::vector<HitInfo> thi(nrays);
+        std::vector<uint8_t> thit(nrays);
+        const auto t0 = Clk::now();
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; t++)
+                pool.emplace_back([&, t] {
+                    for (uint32_t i = (uint32_t)t; i < nrays; i += (uint32_t)nthreads) thit[i] = bvh.intersect(tr[i], thi[i]) ? 1 : 0;
+                });
+            for (std::thread& th : pool) th.join();
+        }
+        const double wall_us = std::chrono::duration<double, std::micro>(Clk::now() - t0).count();
+        int bad = 0;
+        for (uint32_t i = 0; i < nrays; i++) {
+            bad += thit[i] != bhit[i];
+            bad += std::memcmp(&tr[i].t, &batch[i].t, 4) != 0;
+            if (bhit[i]) {
+                bad += std::memcmp(&thi[i].normal, &bhi[i].normal, 12) != 0;
+                bad += std::memcmp(&thi[i].material, &bhi[i].material, sizeof(Material)) != 0;
+            }
+        }
+        if (timing) {
+            timing[0] = single_us;
+            timing[1] = wall_us * nthreads / (nrays ? nrays : 1);
+            timing[2] = nrays / (wall_us * 1e-6);
+        }
+        return bad;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Loader -> scene -> device render -> Screen -> BMP, end to end: `nreplicas` BVH replicas on device 0 (> 1: the frame is
+// split over them like over that many GPUs, renderRayTracingOnDevices), the frame goes through Screen::setPixel (y flip,
+// screen.cpp:30-36) and writeBitmapToFile (:38-49).  rgb_out (optional): the float frame before Screen, index y*W+x.
+int cgrt_host_render_bmp(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
+                         const float* materials, uint32_t nmesh, const float* lights, uint32_t nlights, const float* cam, int W, int H,
+                         int maxLevel, int nreplicas, const char* path, float* rgb_out) {
+    try {
+        Scene sc = scene_from_arrays(pos_nrm, nverts, tri, tri_mesh, ntris, materials, nmesh, lights, nlights);
+        std::vector<std::unique_ptr<BoundingVolumeHierarchy>> own;
+        std::vector<const BoundingVolumeHierarchy*> bvhs;
+        for (int i = 0; i < (nreplicas < 1 ? 1 : nreplicas); i++) {
+            own.emplace_back(new BoundingVolumeHierarchy(&sc, 0));
+            bvhs.push_back(own.back().get());
+        }
+        Trackball camera(cam[7], cam[8], cam[6]);
+        camera.setCamera(cgrt::vec3(cam[0], cam[1], cam[2]), cgrt::vec3(cam[3], cam[4], cam[5]), cam[6]);
+        Screen screen(W, H);
+        if (rgb_out) (void)renderToBufferOnDevices(sc, camera, bvhs, W, H, rgb_out, maxLevel);
+        (void)renderRayTracingOnDevices(sc, camera, bvhs, screen, maxLevel);
         screen.writeBitmapToFile(path);
         return 0;
     } catch (const std::exception& e) {

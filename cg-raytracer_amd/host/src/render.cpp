@@ -251,9 +251,10 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
     return st;
 }
 
-RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
-                                   int maxLevel, const SoftShadowSampler* sampler) {
+RenderStats renderToBufferOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs, int W, int H,
+                                    float* rgb, int maxLevel, const SoftShadowSampler* sampler) {
     const auto t_begin = Clock::now();
+    if (bvhs.empty()) throw std::runtime_error("renderToBufferOnDevices: no BVH replica");
     SoftShadowSampler fallback;
     if (!scene.sphericalLight.empty() && (!sampler || sampler->units.empty() || sampler->samples == 0)) {
         fallback = SoftShadowSampler::gaussian();
@@ -277,9 +278,14 @@ RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, 
     }
     CgrtRenderStats cs{};
     const CgrtCamera cam = camera.abi();
-    if (cgrt_render_soft(bvh.handle(), &cam, W, H, lights.data(), (uint32_t)scene.pointLights.size(), spherical.empty() ? nullptr : &soft, maxLevel, rgb,
-                         &cs) != 0)
-        throw std::runtime_error(std::string("cgrt_render_soft: ") + cgrt_last_error());
+    std::vector<CgrtScene*> handles;
+    for (const BoundingVolumeHierarchy* b : bvhs) handles.push_back(b->handle());
+    const int rc = handles.size() == 1
+                       ? cgrt_render_soft(handles[0], &cam, W, H, lights.data(), (uint32_t)scene.pointLights.size(), spherical.empty() ? nullptr : &soft,
+                                          maxLevel, rgb, &cs)
+                       : cgrt_render_multi(handles.data(), (int)handles.size(), &cam, W, H, lights.data(), (uint32_t)scene.pointLights.size(),
+                                           spherical.empty() ? nullptr : &soft, maxLevel, rgb, &cs);
+    if (rc != 0) throw std::runtime_error(std::string("cgrt_render: ") + cgrt_last_error());
     RenderStats st;
     st.primary = cs.primary_rays;
     st.shadow = cs.shadow_rays;
@@ -287,6 +293,24 @@ RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, 
     st.softShadow = cs.soft_shadow_rays;
     st.seconds_device = cs.device_ms * 1e-3;
     st.seconds_total = std::chrono::duration<double>(Clock::now() - t_begin).count();
+    return st;
+}
+
+RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
+                                   int maxLevel, const SoftShadowSampler* sampler) {
+    return renderToBufferOnDevices(scene, camera, {&bvh}, W, H, rgb, maxLevel, sampler);
+}
+
+RenderStats renderRayTracingOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs,
+                                      Screen& screen, int maxLevel, const SoftShadowSampler* sampler) {
+    const int W = screen.width(), H = screen.height();
+    std::vector<float> rgb((size_t)W * H * 3);
+    RenderStats st = renderToBufferOnDevices(scene, camera, bvhs, W, H, rgb.data(), maxLevel, sampler);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float* p = &rgb[3 * ((size_t)y * W + x)];
+            screen.setPixel(x, y, cgrt::vec3(p[0], p[1], p[2]));  // main.cpp:696
+        }
     return st;
 }
 

@@ -1,17 +1,28 @@
 // Headless stand-in for the reference's interactive main() (src/main.cpp:722-939): load a scene preset or an OBJ,
 // build the BVH, render with the reference's default camera, write render.bmp, print the timing the reference prints
 // (main.cpp:791-797).
-//   render <data-dir> <triangle|cube|cornell|monkey|dragon|custom|file.obj> [W H [maxLevel [out.bmp]]]
+//   render [--gpus N] <data-dir> <triangle|cube|cornell|monkey|dragon|custom|file.obj> [W H [maxLevel [out.bmp]]]
+// --gpus N: the frame is split over N devices (replica i on device i % cgrt_device_count(), super-tiles i % N), the whole
+// shading driver on the devices, one Screen (renderRayTracingOnDevices).
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 
 #include "render.h"
 
+extern "C" int cgrt_device_count(void);
+
 int main(int argc, char** argv) {
+    int gpus = 0;
+    if (argc > 2 && std::strcmp(argv[1], "--gpus") == 0) {
+        gpus = std::atoi(argv[2]);
+        argv += 2;
+        argc -= 2;
+    }
     if (argc < 3) {
-        std::cerr << "usage: render <data-dir> <scene|file.obj> [W H [maxLevel [out.bmp]]]\n";
+        std::cerr << "usage: render [--gpus N] <data-dir> <scene|file.obj> [W H [maxLevel [out.bmp]]]\n";
         return 2;
     }
     const std::filesystem::path dataDir = argv[1];
@@ -41,8 +52,20 @@ int main(int argc, char** argv) {
         const auto start = std::chrono::high_resolution_clock::now();
         // CGRT_RENDER_ON_DEVICE=1: the whole shading/recursion driver on the GPU instead of the host-driven wavefront
         const char* od = std::getenv("CGRT_RENDER_ON_DEVICE");
-        const RenderStats st = (od && od[0] == '1') ? renderRayTracingOnDevice(scene, camera, bvh, screen, maxLevel)
-                                                     : renderRayTracing(scene, camera, bvh, screen, maxLevel);
+        RenderStats st;
+        if (gpus > 0) {
+            const int ndev = cgrt_device_count() > 0 ? cgrt_device_count() : 1;
+            std::vector<std::unique_ptr<BoundingVolumeHierarchy>> own;
+            std::vector<const BoundingVolumeHierarchy*> bvhs;
+            for (int i = 0; i < gpus; i++) {
+                own.emplace_back(new BoundingVolumeHierarchy(&scene, i % ndev));
+                bvhs.push_back(own.back().get());
+            }
+            st = renderRayTracingOnDevices(scene, camera, bvhs, screen, maxLevel);
+        } else {
+            st = (od && od[0] == '1') ? renderRayTracingOnDevice(scene, camera, bvh, screen, maxLevel)
+                                      : renderRayTracing(scene, camera, bvh, screen, maxLevel);
+        }
         const auto end = std::chrono::high_resolution_clock::now();
         std::cout << "Time to render image: " << std::chrono::duration<float, std::milli>(end - start).count() << " milliseconds" << std::endl;
         std::cout << "BVH levels " << bvh.numLevels() << "; rays: " << st.primary << " primary, " << st.shadow << " shadow, " << st.reflection

@@ -9,6 +9,17 @@
  * Every function that returns int returns 0 on success and a negative CGRT_E_* code on failure;
  * cgrt_last_error() then describes the failure (thread-local string).  There is NO CPU fallback:
  * without a usable HIP device cgrt_scene_create fails with CGRT_E_NO_DEVICE.
+ *
+ * Threads.  The reference calls BoundingVolumeHierarchy::intersect on one const object from an `omp parallel for`
+ * (main.cpp:653-656), so:
+ *   - cgrt_intersect_batch, cgrt_trace_primary, cgrt_generate_rays, cgrt_count_* (host pointers) may be called
+ *     concurrently on ONE scene from any number of threads: each call runs on a private stream with private device
+ *     scratch and pinned staging taken from a per-scene pool and waits for that stream only (no hipMalloc / hipFree /
+ *     hipDeviceSynchronize once the pool has grown to the call sizes in use);
+ *   - the *_device entries only enqueue work on the caller's stream and touch no mutable scene state: concurrent too;
+ *   - cgrt_render* use one per-scene workspace: calls on the same scene are serialised by a mutex inside the library;
+ *   - cgrt_set_* are process-wide options (mutex / atomic inside); cgrt_scene_set_walk and cgrt_scene_destroy must not
+ *     race with calls on that scene.
  */
 #ifndef CGRT_H
 #define CGRT_H
@@ -129,6 +140,13 @@ uint64_t cgrt_device_bytes(const CgrtScene* scene);
  * normals (optional, n x 3) receives hitInfo.normal for rays that hit (left untouched otherwise, as
  * the reference leaves HitInfo untouched on a miss).  Host pointers; synchronous. */
 int cgrt_intersect_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, CgrtHit* hits, float* normals);
+/* intersectRayWithShape(const Mesh&, Ray&, HitInfo&) (ray_tracing.cpp:202-213) for n rays: every triangle is tested, no
+ * tree -- the reference's ground truth over all triangles (its BVH misses hits this loop finds: SURVEY.md F4).
+ *   mesh >= 0: that mesh only (index into the scene's meshes); material_id stays -1, the loop never writes hitInfo.material.
+ *   mesh <  0: every mesh in load order, then the spheres, material written: the pre-BVH body of
+ *              BoundingVolumeHierarchy::intersect (bvh.cpp:854-868, commented out upstream).
+ * Same outputs and conventions as cgrt_intersect_batch; O(n * ntris) work: a validation path, not a fast one. */
+int cgrt_intersect_brute_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, int mesh, CgrtHit* hits, float* normals);
 /* Same, all pointers are DEVICE pointers on the scene's device; asynchronous on `stream`
  * (a hipStream_t, NULL = default stream). */
 int cgrt_intersect_batch_device(CgrtScene* scene, const CgrtRay* d_rays, uint64_t n, CgrtHit* d_hits,
@@ -189,6 +207,27 @@ int cgrt_render_soft(CgrtScene* scene, const CgrtCamera* cam, int W, int H, cons
  * caller passed it; the ranks' frames merge by ownership into exactly the single-rank frame.  soft may be NULL. */
 int cgrt_render_rank(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
                      const CgrtSoftShadows* soft, int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats);
+
+/* One caller, N devices, ONE framebuffer (the reference's renderRayTracing fills one Screen,
+ * main.cpp:648-720, its only parallel construct being rows of that frame, :653-656).  scenes[i] is a replica of the scene
+ * created on its own device (cgrt_scene_create with different `device` arguments; the same device may repeat, every
+ * replica must be a distinct handle).  Replica i traces / renders the 64x64 super-tiles i % nscenes; nothing is exchanged
+ * between devices.  trace: all launches are issued first, each on a private stream of its replica; every device downloads
+ * its pixels with one asynchronous copy and a host thread per replica scatters them into `hits` / `normals` (normals
+ * only where hit == 1).  render: one host thread per replica runs cgrt_render_rank's wavefront into a frame of its own
+ * and the owned pixels are merged into `rgb`; stats: ray counts summed, levels / device_ms = maximum over replicas.
+ * The bytes written equal those of the single-device entries (tested). */
+typedef struct CgrtMultiStats {
+    int32_t replicas;
+    float kernel_ms_max;   /* slowest replica's traversal kernel (HIP events on its stream) */
+    float download_ms_max; /* slowest replica's device -> pinned host copy */
+    double wall_ms;        /* first launch to last pixel scattered, host clock */
+    uint64_t rays[64];     /* pixels traced by each replica */
+} CgrtMultiStats;
+int cgrt_trace_primary_multi(CgrtScene* const* scenes, int nscenes, const CgrtCamera* cam, int W, int H, CgrtHit* hits,
+                             float* normals, CgrtMultiStats* stats);
+int cgrt_render_multi(CgrtScene* const* scenes, int nscenes, const CgrtCamera* cam, int W, int H, const float* lights,
+                      uint32_t nlights, const CgrtSoftShadows* soft, int max_level, float* rgb, CgrtRenderStats* stats);
 
 /* Work counters of the same traversal (separate instrumented launch; not part of any timed region). */
 int cgrt_count_primary(CgrtScene* scene, const CgrtCamera* cam, int W, int H, int x0, int y0, int x1, int y1,

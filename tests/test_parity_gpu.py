@@ -359,6 +359,7 @@ def test_persistent_kernel_same_results(pkg, orc, W, H, nranks):
     sd = pkg.scenes.make_dragon(40_000)
     cam = pkg.scenes.default_camera(W, H)
     sc = pkg.Scene(sd)
+    sc.set_walk(False)  # the persistent variant walks exactly; its step counts are compared with the exact walk's
     ref = orc.OracleScene(sd).intersect(sc.generate_rays(cam, W, H))
     try:
         for rank in range(nranks):
@@ -392,7 +393,8 @@ def test_counters_match_oracle_replay(pkg, orc):
     finally:
         pkg.set_leaf_accel(True)
     acc = pkg.Scene(sd)
-    assert lin.num_subnodes() == 0 and acc.num_subnodes() > 0
+    acc.set_walk(False)  # the exact walk is the one that takes the reference's steps (the certified walk has none to count)
+    assert lin.num_subnodes() == 0 and acc.num_subnodes() > 0 and lin.walk() == 0
     got = lin.count_primary(cam, W, H)
     assert got["rays"] == W * H and got["sub_visits"] == 0
     assert got["inner_visits"] == cnt["inner_visits"] and got["leaf_visits"] == cnt["leaf_visits"]
