@@ -98,7 +98,7 @@ CameraDev make_camera(const CgrtCamera& c) {
     return d;
 }
 
-bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nranks, FrameDev& F) {
+bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nranks, int block, FrameDev& F) {
     if (W <= 0 || H <= 0 || x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1 || nranks <= 0 || rank < 0 || rank >= nranks)
         return false;
     F.W = W;
@@ -115,7 +115,8 @@ bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nran
     F.nranks = nranks;
     const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
     F.nst_rank = (uint32_t)((nst + (uint64_t)nranks - 1 - (uint64_t)rank) / (uint64_t)nranks);
-    F.nblocks = ((F.nst_rank + 7u) / 8u) * 8u * 16u;
+    F.block = block;
+    F.nblocks = ((F.nst_rank + 7u) / 8u) * 8u * (64u / ((uint32_t)block / 64u));
     F.packed = 0;
     return true;
 }
@@ -710,7 +711,7 @@ int cgrt_trace_primary_device(CgrtScene* s, const CgrtCamera* cam, int W, int H,
     if (!s || !cam || !d_hits) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     FrameDev F;
-    if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
+    if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, trace_block(s->dev), F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
     HIP_TRY(hipSetDevice(s->device));
     return launch_primary(s, make_camera(*cam), F, reinterpret_cast<CgrtHitDev*>(d_hits), d_normals, nullptr, static_cast<hipStream_t>(stream));
 }
@@ -747,7 +748,7 @@ int cgrt_generate_rays(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     if (!s || !cam || !rays) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     FrameDev F;
-    if (!make_frame(W, H, x0, y0, x1, y1, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame rectangle");
+    if (!make_frame(W, H, x0, y0, x1, y1, 0, 1, CGRT_BLOCK, F)) return fail(CGRT_E_ARG, "bad frame rectangle");
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = (size_t)(x1 - x0) * (size_t)(y1 - y0);
     if (!n) return CGRT_OK;
@@ -784,7 +785,7 @@ int cgrt_count_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     if (!s || !cam || !out) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     FrameDev F;
-    if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
+    if (!make_frame(W, H, x0, y0, x1, y1, rank, nranks, trace_block(s->dev), F)) return fail(CGRT_E_ARG, "bad frame rectangle or rank");
     HIP_TRY(hipSetDevice(s->device));
     LaneGuard g(s);
     int rc = g.acquire();
@@ -801,8 +802,8 @@ int cgrt_debug_wave_times(CgrtScene* s, const CgrtCamera* cam, int W, int H, uin
     if (!s || !cam || !out) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     FrameDev F;
-    if (!make_frame(W, H, 0, 0, W, H, 0, 1, F)) return fail(CGRT_E_ARG, "bad frame");
-    const size_t nwaves = (size_t)F.nblocks * 4;
+    if (!make_frame(W, H, 0, 0, W, H, 0, 1, trace_block(s->dev), F)) return fail(CGRT_E_ARG, "bad frame");
+    const size_t nwaves = (size_t)F.nblocks * (size_t)(F.block / 64);
     if (cap_waves < nwaves) return fail(CGRT_E_ARG, "output too small");
     HIP_TRY(hipSetDevice(s->device));
     DevBuf dh, ds;
@@ -851,8 +852,8 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     const unsigned L = nlights;
     CgrtRenderStats st{};
     FrameDev F;
-    if (!make_frame(W, H, 0, 0, W, H, rank, nranks, F)) return fail(CGRT_E_ARG, "bad frame or rank");
-    const unsigned long long n = (unsigned long long)F.nblocks * 256ull;  // items: this rank's part of the frame in the primary kernel's order
+    if (!make_frame(W, H, 0, 0, W, H, rank, nranks, trace_block(s->dev), F)) return fail(CGRT_E_ARG, "bad frame or rank");
+    const unsigned long long n = (unsigned long long)F.nblocks * (unsigned long long)F.block;  // items: this rank's part of the frame in the primary kernel's order
     // Every level is a compact list: level 0 = the primary rays that hit, level l + 1 = the mirror rays of level l (at most
     // one per entry, so the number of primary hits bounds every list, and n bounds that); the shadow list of a level
     // holds at most entries * L rays.  hits/normals/rays/pixels alternate between two sets (a level's mirror batch is
@@ -1012,11 +1013,12 @@ namespace {
 // pixel of lane (r, c) = row r, column c of the 8x8 tile of wave w of workgroup b: the host mirror of tile_pixel_of()
 inline bool tile_origin(const FrameDev& F, uint32_t b, uint32_t w, int& x, int& y) {
     const uint32_t lane8 = b & 7u, j = b >> 3;
-    const uint32_t sl = (j >> 4) * 8u + lane8;
+    const uint32_t wpb = (uint32_t)F.block / 64u, bps = 64u / wpb;
+    const uint32_t sl = (j / bps) * 8u + lane8;
     if (sl >= F.nst_rank) return false;
     const uint32_t st = (uint32_t)F.rank + (uint32_t)F.nranks * sl;
     const int stx = (int)(st % (uint32_t)F.st_x), sty = (int)(st / (uint32_t)F.st_x);
-    const int idx = (int)(j & 15u) * 4 + (int)w;
+    const int idx = (int)((j % bps) * wpb + w);
     x = F.x0 + (stx * ST_TILES + (idx & 7)) * 8;
     y = F.y0 + (sty * ST_TILES + (idx >> 3)) * 8;
     return x < F.x1 && y < F.y1;
@@ -1050,9 +1052,9 @@ int cgrt_trace_primary_multi(CgrtScene* const* scenes, int nscenes, const CgrtCa
     const auto t_begin = std::chrono::steady_clock::now();
     for (int i = 0; i < nscenes; i++) {  // issue everything, wait for nothing
         Part& P = part[i];
-        if (!make_frame(W, H, 0, 0, W, H, i, nscenes, P.F)) return fail(CGRT_E_ARG, "bad frame");
+        if (!make_frame(W, H, 0, 0, W, H, i, nscenes, trace_block(scenes[i]->dev), P.F)) return fail(CGRT_E_ARG, "bad frame");
         P.F.packed = 1;
-        P.n = (size_t)P.F.nblocks * 256u;
+        P.n = (size_t)P.F.nblocks * (size_t)P.F.block;
         if (P.n == 0) continue;
         HIP_TRY(hipSetDevice(scenes[i]->device));
         P.g = new LaneGuard(scenes[i]);
@@ -1089,11 +1091,11 @@ int cgrt_trace_primary_multi(CgrtScene* const* scenes, int nscenes, const CgrtCa
         const CgrtHit* ph = static_cast<const CgrtHit*>(P.ph);
         const float* pn = static_cast<const float*>(P.pn);
         for (uint32_t b = 0; b < P.F.nblocks; b++)
-            for (uint32_t w = 0; w < 4; w++) {
+            for (uint32_t w = 0; w < (uint32_t)P.F.block / 64u; w++) {
                 int x, y;
                 if (!tile_origin(P.F, b, w, x, y)) continue;
                 const int cw = std::min(8, P.F.x1 - x), ch = std::min(8, P.F.y1 - y);
-                const size_t base = (size_t)b * 256u + w * 64u;
+                const size_t base = (size_t)b * (size_t)P.F.block + w * 64u;
                 for (int r = 0; r < ch; r++) {
                     std::memcpy(hits + (size_t)(y + r) * W + x, ph + base + 8 * r, (size_t)cw * sizeof(CgrtHit));
                     if (normals) {
@@ -1167,7 +1169,7 @@ int cgrt_render_multi(CgrtScene* const* scenes, int nscenes, const CgrtCamera* c
     CgrtRenderStats tot{};
     for (int i = 0; i < nscenes; i++) {
         FrameDev F;
-        make_frame(W, H, 0, 0, W, H, i, nscenes, F);
+        make_frame(W, H, 0, 0, W, H, i, nscenes, CGRT_BLOCK, F);
         const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
         for (uint64_t k = (uint64_t)i; k < nst; k += (uint64_t)nscenes) {
             const int sx = (int)(k % (uint64_t)F.st_x) * 64, sy = (int)(k / (uint64_t)F.st_x) * 64;

@@ -146,10 +146,17 @@ struct FrameDev {
     int st_x, st_y;        // super-tiles covering the rectangle
     int rank, nranks;
     uint32_t nst_rank;     // super-tiles this rank owns
-    uint32_t nblocks;      // 256-thread workgroups launched: 16 per super-tile, super-tiles padded to 8
-    int packed;            // 1: results are written at blockIdx * 256 + threadIdx (the rank's pixels back to back, in the kernel's
+    int block;             // threads per workgroup of the launch (64, 128 or 256)
+    uint32_t nblocks;      // workgroups launched: 64 / (block / 64) per super-tile, super-tiles padded to 8
+    int packed;            // 1: results are written at blockIdx * block + threadIdx (the rank's pixels back to back, in the kernel's
                            // own order: one contiguous download per device) instead of at y * W + x
 };
 static const int ST_TILES = 8;  // tiles per super-tile side
+// Workgroups of the traversal kernels hold 64, 128 or 256 threads (chosen per launch: FrameDev::block, blockDim.x): one wave
+// per 8x8 tile, so a 64x64 super-tile takes 64 / (block / 64) consecutive workgroups of one blockIdx % 8 residue.  CGRT_BLOCK
+// is the largest size (launch bounds).  The per-lane stacks are laid out per WAVE -- slot s of lane l of wave w at
+// w * CGRT_STACK_SLOTS * 64 + s * 64 + l -- so that the walk code does not depend on the workgroup size.
+#define CGRT_BLOCK 256
+#define CGRT_STRIDE 64
 
 }  // namespace cgrt

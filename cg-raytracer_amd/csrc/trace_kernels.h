@@ -24,6 +24,8 @@ struct SoftDev {
     uint32_t nlights, samples, nunits, seed, level;
 };
 
+// threads per workgroup the ray-list kernels (batch, soft shadow) are launched with for this scene; frames carry theirs in FrameDev::block
+int trace_block(const SceneDev& S);
 // counters (optional): 5 x u64 device words {rays, inner_visits, leaf_visits, tri_tests, sub_visits}, accumulated.
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
                                 unsigned long long* counters, hipStream_t stream);

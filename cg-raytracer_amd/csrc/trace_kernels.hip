@@ -17,8 +17,7 @@ namespace cgrt {
 template <bool COUNT, bool FAST>
 __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                         unsigned long long* counters) {
-    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
-    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
+    extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
@@ -27,9 +26,9 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
     float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
     uint32_t hit_rec = REF_NONE;
-    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (active) {
-        const size_t pix = F.packed ? (size_t)blockIdx.x * CGRT_BLOCK + threadIdx.x : (size_t)y * F.W + x;
+        const size_t pix = F.packed ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
     if (COUNT) flush_counters(cnt, active, counters);
@@ -42,8 +41,7 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
 template <bool FAST>
 __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
                                                 float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count) {
-    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
-    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
+    extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
@@ -54,28 +52,28 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
     float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
     uint32_t hit_rec = REF_NONE;
-    walk_tree<false, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    walk_tree<false, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (active) resolve_hit(S, o, d, t, hit_rec, true, h, nn);
     // one atomic per workgroup (same-address atomics serialise at the L2); the workgroup's LDS is only released when its
     // last wave ends anyway, so waiting for it here costs no occupancy
     const bool keep = active && h.hit != 0;
     const unsigned long long m = __ballot(keep);
-    __shared__ uint32_t s_cnt[CGRT_BLOCK / 64 + 1];
-    const unsigned w = threadIdx.x >> 6;
+    uint32_t* s_cnt = CGRT_BLOCK_SCRATCH(s_lds);
+    const unsigned w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
-        for (unsigned k = 0; k < CGRT_BLOCK / 64; k++) {
+        for (unsigned k = 0; k < nw; k++) {
             const uint32_t c = s_cnt[k];
             s_cnt[k] = tot;
             tot += c;
         }
-        s_cnt[CGRT_BLOCK / 64] = tot ? atomicAdd(count, tot) : 0u;
+        s_cnt[nw] = tot ? atomicAdd(count, tot) : 0u;
     }
     __syncthreads();
     if (keep) {
-        const unsigned long long idx = s_cnt[CGRT_BLOCK / 64] + s_cnt[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long idx = s_cnt[nw] + s_cnt[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         float* r = rays + 7 * idx;
         r[0] = o.x;
         r[1] = o.y;
@@ -104,9 +102,8 @@ template <bool COUNT, bool FAST>
 __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                                             unsigned long long* counters, const uint32_t* __restrict__ dcount) {
-    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
-    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
-    const unsigned long long i = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
+    extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (dcount) {
         const unsigned long long present = *dcount;
         n = present < n ? present : n;
@@ -122,7 +119,7 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
         t = r[6];
     }
     uint32_t hit_rec = REF_NONE;
-    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (active) finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
     if (COUNT) flush_counters(cnt, active, counters);
 }
@@ -136,9 +133,8 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
 template <bool ANYHIT, bool FAST>
 __global__ CGRT_LB void k_soft_shadow(SceneDev S, SoftDev Q, const float* __restrict__ rays, const CgrtHitDev* __restrict__ hits,
                                       const int* __restrict__ item_pixels, unsigned long long nthreads, uint32_t* __restrict__ lit) {
-    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
-    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];  // quad tail: owner lanes of a wave's live rays (walk_fast.h)
-    const unsigned long long g = (unsigned long long)blockIdx.x * CGRT_BLOCK + threadIdx.x;
+    extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
+    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = g < nthreads;
     const unsigned long long key = in ? g / Q.samples : 0ull;  // item * nlights + l
     const uint32_t smp = in ? (uint32_t)(g - key * Q.samples) : 0u;
@@ -158,7 +154,7 @@ __global__ CGRT_LB void k_soft_shadow(SceneDev S, SoftDev Q, const float* __rest
     const float lightT = t;
     uint32_t hit_rec = REF_NONE;
     LaneCounters cnt;
-    walk_tree<false, FAST, ANYHIT>(S, live, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    walk_tree<false, FAST, ANYHIT>(S, live, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (live) {
         bool hit = hit_rec != REF_NONE;
         if (!ANYHIT || !hit) {  // spheres come after the meshes in BoundingVolumeHierarchy::intersect (bvh.cpp:875-880)
@@ -201,15 +197,27 @@ __global__ __launch_bounds__(CGRT_BLOCK) void k_generate_rays(CameraDev C, int W
 }
 // ---------------------------------------------------------------------------------------------
 // launchers (host).  A scene with a fast tree (SceneDev::fast_root) takes the FAST instantiations; the C-ABI clears
-// fast_root in its copy of SceneDev to force the exact walk (cgrt_scene_set_walk).
+// fast_root in its copy of SceneDev to force the exact walk (cgrt_scene_set_walk).  Workgroup size: FrameDev::block for
+// frames, trace_block() for ray lists -- 64 threads (one wave, its LDS released the moment it ends) for the certified walk,
+// whose waves differ widely in length; 256 for the exact walk (measured: profiles/r2_exp_block_size.txt).
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(unsigned long long n, unsigned block) { return (unsigned)((n + block - 1) / block); }
-#define CGRT_LAUNCH2(KERNEL, A, fast, grid, lds, stream, ...)                                                       \
-    do {                                                                                                              \
-        if (fast)                                                                                                     \
-            hipLaunchKernelGGL((KERNEL<A, true>), dim3(grid), dim3(CGRT_BLOCK), lds, stream, __VA_ARGS__);           \
-        else                                                                                                          \
-            hipLaunchKernelGGL((KERNEL<A, false>), dim3(grid), dim3(CGRT_BLOCK), lds, stream, __VA_ARGS__);          \
+static inline size_t lds_bytes(unsigned block) { return sizeof(uint32_t) * (size_t)CGRT_LDS_WORDS(block); }
+int trace_block(const SceneDev& S) {
+    static const int forced = [] {
+        const char* e = getenv("CGRT_BLOCK_THREADS");  // experiment knob: 64 / 128 / 256
+        const int v = e ? atoi(e) : 0;
+        return (v == 64 || v == 128 || v == 256) ? v : 0;
+    }();
+    if (forced) return forced;
+    return S.fast_root != REF_NONE ? 64 : 256;
+}
+#define CGRT_LAUNCH2(KERNEL, A, fast, grid, block, stream, ...)                                                             \
+    do {                                                                                                                      \
+        if (fast)                                                                                                             \
+            hipLaunchKernelGGL((KERNEL<A, true>), dim3(grid), dim3(block), lds_bytes(block), stream, __VA_ARGS__);           \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((KERNEL<A, false>), dim3(grid), dim3(block), lds_bytes(block), stream, __VA_ARGS__);          \
     } while (0)
 
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
@@ -217,47 +225,50 @@ hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const Fra
     if (F.nblocks == 0) return hipSuccess;
     const bool fast = S.fast_root != REF_NONE;
     if (counters)
-        CGRT_LAUNCH2(k_trace_primary, true, fast, F.nblocks, 0, stream, S, C, F, hits, normals, counters);
+        CGRT_LAUNCH2(k_trace_primary, true, fast, F.nblocks, (unsigned)F.block, stream, S, C, F, hits, normals, counters);
     else
-        CGRT_LAUNCH2(k_trace_primary, false, fast, F.nblocks, 0, stream, S, C, F, hits, normals, counters);
+        CGRT_LAUNCH2(k_trace_primary, false, fast, F.nblocks, (unsigned)F.block, stream, S, C, F, hits, normals, counters);
     return hipGetLastError();
 }
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
                               unsigned long long* counters, hipStream_t stream, const uint32_t* dcount) {
     if (n == 0) return hipSuccess;
-    const unsigned blocks = grid_for(n, CGRT_BLOCK);
+    const unsigned block = (unsigned)trace_block(S);
+    const unsigned blocks = grid_for(n, block);
     const bool fast = S.fast_root != REF_NONE;
     if (counters)
-        CGRT_LAUNCH2(k_trace_batch, true, fast, blocks, 0, stream, S, rays, n, hits, normals, counters, dcount);
+        CGRT_LAUNCH2(k_trace_batch, true, fast, blocks, block, stream, S, rays, n, hits, normals, counters, dcount);
     else
-        CGRT_LAUNCH2(k_trace_batch, false, fast, blocks, 0, stream, S, rays, n, hits, normals, counters, dcount);
+        CGRT_LAUNCH2(k_trace_batch, false, fast, blocks, block, stream, S, rays, n, hits, normals, counters, dcount);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
                                         int* pixels, uint32_t* count, hipStream_t stream) {
     if (F.nblocks == 0) return hipSuccess;
+    const unsigned block = (unsigned)F.block;
     if (S.fast_root != REF_NONE)
-        hipLaunchKernelGGL(k_trace_primary_compact<true>, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, rays, hits, normals, pixels, count);
+        hipLaunchKernelGGL(k_trace_primary_compact<true>, dim3(F.nblocks), dim3(block), lds_bytes(block), stream, S, C, F, rays, hits, normals, pixels, count);
     else
-        hipLaunchKernelGGL(k_trace_primary_compact<false>, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, rays, hits, normals, pixels, count);
+        hipLaunchKernelGGL(k_trace_primary_compact<false>, dim3(F.nblocks), dim3(block), lds_bytes(block), stream, S, C, F, rays, hits, normals, pixels, count);
     return hipGetLastError();
 }
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream) {
     if (F.nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_clear_owned, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, F, rgb);
+    hipLaunchKernelGGL(k_clear_owned, dim3(F.nblocks), dim3((unsigned)F.block), 0, stream, F, rgb);
     return hipGetLastError();
 }
 hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
                               unsigned long long nitems, uint32_t* lit, int anyhit, hipStream_t stream) {
     const unsigned long long nthreads = nitems * Q.nlights * Q.samples;
     if (nthreads == 0) return hipSuccess;
-    const unsigned long long blocks = (nthreads + CGRT_BLOCK - 1) / CGRT_BLOCK;
+    const unsigned block = (unsigned)trace_block(S);
+    const unsigned long long blocks = (nthreads + block - 1) / block;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const bool fast = S.fast_root != REF_NONE;
     if (anyhit)
-        CGRT_LAUNCH2(k_soft_shadow, true, fast, (unsigned)blocks, 0, stream, S, Q, rays, hits, item_pixels, nthreads, lit);
+        CGRT_LAUNCH2(k_soft_shadow, true, fast, (unsigned)blocks, block, stream, S, Q, rays, hits, item_pixels, nthreads, lit);
     else
-        CGRT_LAUNCH2(k_soft_shadow, false, fast, (unsigned)blocks, 0, stream, S, Q, rays, hits, item_pixels, nthreads, lit);
+        CGRT_LAUNCH2(k_soft_shadow, false, fast, (unsigned)blocks, block, stream, S, Q, rays, hits, item_pixels, nthreads, lit);
     return hipGetLastError();
 }
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream) {

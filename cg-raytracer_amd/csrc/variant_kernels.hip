@@ -18,10 +18,9 @@ namespace cgrt {
 template <bool FAST>
 __global__ CGRT_LB void k_trace_primary_stamped(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits,
                                                 unsigned long long* __restrict__ stamps) {
-    __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
-    __shared__ uint32_t s_map[(CGRT_BLOCK / 64) * 16];
+    extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x)
     const int lane = threadIdx.x & 63;
-    const uint32_t wave_global = blockIdx.x * (CGRT_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
@@ -30,7 +29,7 @@ __global__ CGRT_LB void k_trace_primary_stamped(SceneDev S, CameraDev C, FrameDe
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
     float t = 3.402823466e+38f;
     uint32_t hit_rec = REF_NONE;
-    walk_tree<true, FAST>(S, active, o, d, t, hit_rec, s_stk, s_map + (threadIdx.x >> 6) * 16, cnt);
+    walk_tree<true, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (active) finish_ray(S, o, d, t, hit_rec, hits + ((size_t)y * F.W + x), nullptr);
     const unsigned long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long nactive = __popcll(__ballot(active));
@@ -64,8 +63,8 @@ __device__ __forceinline__ bool walk_topology(const SceneDev& S, Walk& W, uint32
             bool found = false;
             while (sp > 0) {
                 sp -= 2;
-                const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
-                const uint32_t r = stk[sp * CGRT_BLOCK];
+                const float ts = __uint_as_float(stk[(sp + 1) * CGRT_STRIDE]);
+                const uint32_t r = stk[sp * CGRT_STRIDE];
                 if (!(W.t < ts)) {  // bvh.cpp:582: skip the deferred child iff ray.t < tSecond
                     cur = r;
                     found = true;
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
                                                    float* __restrict__ normals, unsigned long long* counters,
                                                    unsigned int* __restrict__ queue, unsigned int total_waves) {
     __shared__ uint32_t s_stk[CGRT_STACK_SLOTS * CGRT_BLOCK];
-    uint32_t* stk = s_stk + threadIdx.x;
+    uint32_t* stk = CGRT_WAVE_STACK(s_stk) + (threadIdx.x & 63u);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t home = blockIdx.x & 7u;
@@ -248,9 +247,9 @@ hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, c
                                         unsigned long long* stamps, hipStream_t stream) {
     if (F.nblocks == 0) return hipSuccess;
     if (S.fast_root != REF_NONE)
-        hipLaunchKernelGGL(k_trace_primary_stamped<true>, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, hits, stamps);
+        hipLaunchKernelGGL(k_trace_primary_stamped<true>, dim3(F.nblocks), dim3((unsigned)F.block), sizeof(uint32_t) * (size_t)CGRT_LDS_WORDS(F.block), stream, S, C, F, hits, stamps);
     else
-        hipLaunchKernelGGL(k_trace_primary_stamped<false>, dim3(F.nblocks), dim3(CGRT_BLOCK), 0, stream, S, C, F, hits, stamps);
+        hipLaunchKernelGGL(k_trace_primary_stamped<false>, dim3(F.nblocks), dim3((unsigned)F.block), sizeof(uint32_t) * (size_t)CGRT_LDS_WORDS(F.block), stream, S, C, F, hits, stamps);
     return hipGetLastError();
 }
 

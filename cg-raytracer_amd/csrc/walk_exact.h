@@ -24,7 +24,6 @@
 
 namespace cgrt {
 
-#define CGRT_BLOCK 256
 // ---- experiment knobs (build variants with -D...; defaults are the shipped configuration) ----
 #ifndef CGRT_MIN_WAVES
 #define CGRT_MIN_WAVES 0  // __launch_bounds__ second argument (waves per SIMD) for the trace kernels, 0 = unset
@@ -41,6 +40,13 @@ namespace cgrt {
 // Per-lane LDS stack, in 4-byte slots: a deferred reference child takes 2 slots (ref, tSecond), at most
 // MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 1 slot (ref), at most SUB_STACK_ENTRIES.
 #define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES)
+// Dynamic LDS of a traversal kernel launched with `block` threads: the waves' stacks, then 16 words per wave for the quad
+// tail's owner map (walk_fast.h), then block / 64 + 1 words of workgroup scratch.
+#define CGRT_LDS_WORDS(block) ((block) * CGRT_STACK_SLOTS + ((block) / 64) * 16 + (block) / 64 + 1)
+// this wave's stack region / owner map inside the dynamic LDS array `lds`
+#define CGRT_WAVE_STACK(lds) ((lds) + (threadIdx.x >> 6) * (CGRT_STACK_SLOTS * 64))
+#define CGRT_WAVE_MAP(lds) ((lds) + blockDim.x * CGRT_STACK_SLOTS + (threadIdx.x >> 6) * 16)
+#define CGRT_BLOCK_SCRATCH(lds) ((lds) + blockDim.x * CGRT_STACK_SLOTS + (blockDim.x >> 6) * 16)
 
 struct LaneCounters {
     uint32_t inner = 0, leaf = 0, tri = 0, sub = 0;
@@ -275,11 +281,11 @@ __device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P
 #undef CGRT_CSWAP
         // Branch-free pushes: the slot is always written and only kept (sp advanced) when the child was hit; a
         // level defers at most three children, so the writes stay inside the lane's SUB_STACK_ENTRIES slots.
-        stk[sp * CGRT_BLOCK] = r3;
+        stk[sp * CGRT_STRIDE] = r3;
         sp += (k3 < inf) ? 1 : 0;
-        stk[sp * CGRT_BLOCK] = r2;
+        stk[sp * CGRT_STRIDE] = r2;
         sp += (k2 < inf) ? 1 : 0;
-        stk[sp * CGRT_BLOCK] = r1;
+        stk[sp * CGRT_STRIDE] = r1;
         sp += (k1 < inf) ? 1 : 0;
         cur = (k0 < inf) ? r0 : REF_NONE;
     }
@@ -308,7 +314,7 @@ __device__ __forceinline__ void scan_leaf(const SceneDev& S, const LeafRec LR, c
             // ---- pop ----
             if (sp <= sp0) break;
             sp -= 1;
-            cur = stk[sp * CGRT_BLOCK];
+            cur = stk[sp * CGRT_STRIDE];
         }
     }
     if (L.onp_k >= 0) {
@@ -454,8 +460,8 @@ __device__ __forceinline__ void topo_step(const SceneDev& S, const Walk& W, cons
         const float tsec = (inL && inR) ? -__builtin_inff() : (lfirst ? tR : tL);
         // branch-free push: the two slots above sp are always written and only kept when a child was deferred
         // (at most MAX_LEVELS - 1 deferred children exist at any time, so the slots are inside the lane's slice)
-        stk[sp * CGRT_BLOCK] = second;
-        stk[(sp + 1) * CGRT_BLOCK] = __float_as_uint(tsec);
+        stk[sp * CGRT_STRIDE] = second;
+        stk[(sp + 1) * CGRT_STRIDE] = __float_as_uint(tsec);
         sp += (second != REF_NONE) ? 2 : 0;
         cur = first;
     };
@@ -484,8 +490,8 @@ __device__ __forceinline__ void topo_step(const SceneDev& S, const Walk& W, cons
 __device__ __forceinline__ bool topo_pop(const float t, uint32_t& cur, int& sp, const uint32_t* __restrict__ stk) {
     while (sp > 0) {
         sp -= 2;
-        const uint32_t r = stk[sp * CGRT_BLOCK];  // both words in one LDS access (ds_read2st64_b32)
-        const float ts = __uint_as_float(stk[(sp + 1) * CGRT_BLOCK]);
+        const uint32_t r = stk[sp * CGRT_STRIDE];  // both words in one LDS access (ds_read2st64_b32)
+        const float ts = __uint_as_float(stk[(sp + 1) * CGRT_STRIDE]);
         asm volatile("" : : "v"(r), "v"(ts));  // keeps the pair together: the reference is wanted whenever ts passes
         if (!(t < ts)) {
             cur = r;
@@ -561,7 +567,7 @@ __device__ __forceinline__ void walk_tree_unified(const SceneDev& S, Walk& W, ui
         if (sp0 >= 0 && scur == REF_NONE) {
             if (sp > sp0) {
                 sp -= 1;
-                scur = stk[sp * CGRT_BLOCK];
+                scur = stk[sp * CGRT_STRIDE];
             } else {  // commit the scan (intersectLeaf's outcome) and return to the topology
                 if (L.onp_k >= 0) {
                     W.t = 0.0f;
@@ -667,11 +673,12 @@ __device__ __forceinline__ void primary_ray(const CameraDev& C, int W, int H, in
 __device__ __forceinline__ bool tile_pixel_of(const FrameDev& F, const uint32_t b, const uint32_t tid, int& x, int& y) {
     const uint32_t lane8 = b & 7u, j = b >> 3;
     const int lane = (int)(tid & 63u);
-    const uint32_t s = (j >> 4) * 8u + lane8;  // rank-local super-tile
+    const uint32_t wpb = blockDim.x >> 6, bps = 64u / wpb;  // waves per workgroup, workgroups per super-tile
+    const uint32_t s = (j / bps) * 8u + lane8;  // rank-local super-tile
     if (s >= F.nst_rank) return false;
     const uint32_t st = (uint32_t)F.rank + (uint32_t)F.nranks * s;
     const int stx = (int)(st % (uint32_t)F.st_x), sty = (int)(st / (uint32_t)F.st_x);
-    const int idx = (int)(j & 15u) * 4 + (int)(tid >> 6);
+    const int idx = (int)((j % bps) * wpb + (tid >> 6));
     const int tx = stx * ST_TILES + (idx & 7), ty = sty * ST_TILES + (idx >> 3);
     x = F.x0 + tx * 8 + (lane & 7);
     y = F.y0 + ty * 8 + (lane >> 3);

@@ -72,12 +72,13 @@ __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W,
     const uint32_t n = S.leaves[leaf].path_len;
     const float2* pb = reinterpret_cast<const float2*>(S.paths + (size_t)leaf * (PATH_BOXES * 6));
     if (COUNT) cnt.cert += n;
+    const RayFast R = make_rayfast(S, W.o, W.d);  // (recomputed here rather than kept in registers through the search)
     bool ok = true;
     for (uint32_t i = 0; i < n; i++) {
         const float2 a = pb[3 * i], b = pb[3 * i + 1], c = pb[3 * i + 2];
         float tb;
         bool inside;
-        const bool hit = ray_box_fast<true>(f3(a.x, a.y, b.x), f3(b.y, c.x, c.y), W.o, W.d, W.R, t, tb, inside);
+        const bool hit = ray_box_fast<true>(f3(a.x, a.y, b.x), f3(b.y, c.x, c.y), W.o, W.d, R, t, tb, inside);
         ok = ok && (hit || inside);
     }
     return ok;
@@ -126,14 +127,14 @@ __device__ __forceinline__ void quad_merge(float& bt, uint32_t& br, bool& tie, c
 // On return the owners hold their ray's final FastScan and `failed`.
 template <bool COUNT, bool ANYHIT>
 __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long long live, const bool mine, const Walk& W, FastScan& F,
-                                          uint32_t cur, int sp, bool& failed, uint32_t* __restrict__ s_stk_block, uint32_t* __restrict__ s_map,
+                                          uint32_t cur, int sp, bool& failed, uint32_t* __restrict__ wave_stk, uint32_t* __restrict__ s_map,
                                           LaneCounters& cnt) {
     const int lane = threadIdx.x & 63;
     const int myrank = __popcll(live & ((1ull << lane) - 1ull));
-    uint32_t* __restrict__ my = s_stk_block + threadIdx.x;
+    uint32_t* __restrict__ my = wave_stk + lane;
     if (mine) {
         if (cur != REF_NONE) {  // the node or run the lane stands on goes back on its stack
-            my[sp * CGRT_BLOCK] = cur;
+            my[sp * CGRT_STRIDE] = cur;
             sp += 1;
         }
         s_map[myrank] = (uint32_t)lane;
@@ -163,7 +164,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
     G.failed = false;
     const int osp = __shfl(sp, src, 64);  // (unconditional: a shuffle only sees lanes that execute it)
     int qsp = valid ? osp : 0;
-    uint32_t* __restrict__ stk = s_stk_block + ((threadIdx.x & ~63u) + (uint32_t)src);  // the owner's LDS slice
+    uint32_t* __restrict__ stk = wave_stk + src;  // the owner's LDS slice
     const float inf = __builtin_inff();
     while (__any(qsp > 0)) {
         // entries this round: up to four, fewer when the survivors (at most 4 per node) might not fit
@@ -174,7 +175,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
             qsp = 0;
         }
         const bool has = q < n;
-        const uint32_t ref = has ? stk[(qsp - 1 - q) * CGRT_BLOCK] : REF_NONE;
+        const uint32_t ref = has ? stk[(qsp - 1 - q) * CGRT_STRIDE] : REF_NONE;
         qsp -= n;
         uint32_t r0 = REF_NONE, r1 = REF_NONE, r2 = REF_NONE, r3 = REF_NONE;
         int c = 0;
@@ -238,10 +239,10 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
         const int c2q = (int)dpp_u32<CGRT_QP_BCAST(2)>((uint32_t)c), c3q = (int)dpp_u32<CGRT_QP_BCAST(3)>((uint32_t)c);
         const int off = (q < 3 ? c3q : 0) + (q < 2 ? c2q : 0) + (q < 1 ? c1q : 0);
         int pos = qsp + off;
-        if (c > 3) stk[(pos++) * CGRT_BLOCK] = r3;
-        if (c > 2) stk[(pos++) * CGRT_BLOCK] = r2;
-        if (c > 1) stk[(pos++) * CGRT_BLOCK] = r1;
-        if (c > 0) stk[(pos++) * CGRT_BLOCK] = r0;
+        if (c > 3) stk[(pos++) * CGRT_STRIDE] = r3;
+        if (c > 2) stk[(pos++) * CGRT_STRIDE] = r2;
+        if (c > 1) stk[(pos++) * CGRT_STRIDE] = r1;
+        if (c > 0) stk[(pos++) * CGRT_STRIDE] = r0;
         qsp += c0q + c1q + c2q + c3q;
         // the scan state, reduced over the quad
         {
@@ -285,9 +286,9 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
 // certified the reference's flag is set too -- had the reference accepted nothing, ray.t would still be the initial one and
 // it would reach that leaf and accept the triangle.
 template <bool COUNT, bool ANYHIT>
-__device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool alive, Walk& W, uint32_t* __restrict__ s_stk_block,
+__device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool alive, Walk& W, uint32_t* __restrict__ wave_stk,
                                                uint32_t* __restrict__ s_map, LaneCounters& cnt) {
-    uint32_t* __restrict__ stk = s_stk_block + threadIdx.x;
+    uint32_t* __restrict__ stk = wave_stk + (threadIdx.x & 63u);
     const F3 o = W.o, d = W.d;
     FastScan F;
     F.best_t = W.t;
@@ -301,7 +302,7 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
         const unsigned long long live = __ballot(!done);
         if (live == 0ull) break;
         if (CGRT_QUAD_TAIL_RAYS > 0 && __popcll(live) <= CGRT_QUAD_TAIL_RAYS) {
-            quad_tail<COUNT, ANYHIT>(S, live, !done, W, F, cur, sp, failed, s_stk_block, s_map, cnt);
+            quad_tail<COUNT, ANYHIT>(S, live, !done, W, F, cur, sp, failed, wave_stk, s_map, cnt);
             break;
         }
         if (!done) {
@@ -315,7 +316,7 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
             if (cur == REF_NONE && !done) {
                 if (sp > 0) {
                     sp -= 1;
-                    cur = stk[sp * CGRT_BLOCK];
+                    cur = stk[sp * CGRT_STRIDE];
                 } else {
                     done = true;
                 }
@@ -332,14 +333,14 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
 }
 
 // BoundingVolumeHierarchy::intersect's mesh part (bvh.cpp:870-875) for the rays of a wave (one per `active` lane; call
-// with all 64 lanes): root gate, then the certified walk when the scene has a fast tree and the ray lies inside both
+// with all 64 lanes; wave_stk / s_map: CGRT_WAVE_STACK / CGRT_WAVE_MAP of the kernel's dynamic LDS): root gate, then the certified walk when the scene has a fast tree and the ray lies inside both
 // envelopes (RayPre::regular, RayFast::fd), the exact walk otherwise or when no certificate was obtained.
 // ANYHIT (exact walk): stop after the first leaf that accepted a triangle.  The walk up to there is the reference's, so the
 // hit FLAG is the reference's (some acceptance happens upstream iff one happens in the first leaf that has one); t and the
 // record are those of that leaf, not the final ones.
 template <bool COUNT, bool FAST, bool ANYHIT = false>
 __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
-                                          uint32_t* __restrict__ s_stk_block, uint32_t* __restrict__ s_map, LaneCounters& cnt) {
+                                          uint32_t* __restrict__ wave_stk, uint32_t* __restrict__ s_map, LaneCounters& cnt) {
     Walk W;
     W.o = o;
     W.d = d;
@@ -350,10 +351,16 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, 
     bool certified = false;
     if (FAST) {
         const bool eligible = entered && W.P.regular && W.R.fd;
-        if (__any(eligible)) certified = walk_fast_wave<COUNT, ANYHIT>(S, eligible, W, s_stk_block, s_map, cnt);
+        if (__any(eligible)) certified = walk_fast_wave<COUNT, ANYHIT>(S, eligible, W, wave_stk, s_map, cnt);
         if (COUNT && eligible && !certified) cnt.fallback++;
     }
-    if (entered && !certified) walk_tree_unified<COUNT, ANYHIT>(S, W, s_stk_block + threadIdx.x, cnt);
+    if (entered && !certified) {
+        if (FAST) {  // (the per-ray constants of the exact walk are rebuilt rather than kept alive through the search)
+            W.P = make_raypre(S, W.o, W.d, W.t);
+            W.R = make_rayfast(S, W.o, W.d);
+        }
+        walk_tree_unified<COUNT, ANYHIT>(S, W, wave_stk + (threadIdx.x & 63u), cnt);
+    }
     t = W.t;
     hit_rec = W.hit_rec;
 }
