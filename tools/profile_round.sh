@@ -1,13 +1,13 @@
 #!/bin/bash
 # Profile of the bench command for profiles/: kernel trace + stats, then PMC passes (each in its own run,
 # --pmc never combined with tracing domains).  Usage on the GPU box:  bash tools/profile_round.sh <tag>
-tag=${1:-r1}
+tag=${1:-r2}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/profile_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_trace.json 2> $out/trace.err || exit 1
-pass() { n=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $out/$n -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/$n.err || exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $out/bench_under_trace.json 2> $out/trace.err || exit 1
+pass() { n=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $out/$n -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> $out/$n.err || exit 1; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass cache TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
@@ -15,7 +15,7 @@ pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_
 python3 - <<PY
 import csv, collections, json, re
 out="$out"
-def mean(path, kernel="k_trace_primary<false"):
+def mean(path, kernel="k_trace_primary<false"):  # the timed instantiation (COUNT = false)
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if kernel in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -30,9 +30,13 @@ bench=json.loads(open(f"{out}/bench_under_trace.json").read())
 fetch_b = res.get("FETCH_SIZE",0)*1024; write_b = res.get("WRITE_SIZE",0)*1024
 summary = {"counters": res, "fetch_bytes_raw": fetch_b, "fetch_bytes_x2_gfx950": 2*fetch_b, "write_bytes": write_b,
            "hbm_bytes_per_launch": fetch_b + write_b,
-           "workload": "dragon%s_%s" % (re.search(r"stand-in (\d+) tris", bench["config"]["workload"]).group(1), re.search(r"(\d+x\d+) primary", bench["config"]["workload"]).group(1)),
+           "workload": "dragon%s_%s_%s" % (re.search(r"stand-in (\d+) tris", bench["config"]["workload"]).group(1), re.search(r"(\d+x\d+) primary", bench["config"]["workload"]).group(1),
+                                            "certified" if "certified" in bench["config"]["workload"] else "exact"),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_round.sh %s" % "$tag",
            "bench_under_trace": {k: bench[k] for k in ("value","ms_per_step")}, "roofline": bench["roofline"]}
 json.dump(summary, open(f"{out}/summary.json","w"), indent=1)
+json.dump({k: summary[k] for k in ("workload", "hbm_bytes_per_launch", "fetch_bytes_raw", "write_bytes", "source")} | {"note": "FETCH_SIZE calibrated for this access shape (scattered 64-B records, 16 B per lane per instruction): counter/known = 1.0000 (profiles/r1_fetch_size_calibration.txt), so no gfx950 x2 correction applies"},
+          open(f"{out}/hbm_traffic_latest.json","w"), indent=1)
 print(json.dumps(summary)[:1500])
 PY
 cat $out/trace/t_kernel_stats.csv | cut -c1-220
