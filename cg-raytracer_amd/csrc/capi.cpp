@@ -945,7 +945,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
                 HIP_TRY(hipEventRecord(aux.traced, aux.s));
             }
             if (L)
-                HIP_TRY(launch_trace_batch(s->dev, srays.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, nullptr, nullptr, ctr + 0));
+                HIP_TRY(launch_trace_shadow(s->dev, srays.as<float>(), sdist.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, ctr + 0));
             if (SL) {
                 Q.level = (uint32_t)level;
                 HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));

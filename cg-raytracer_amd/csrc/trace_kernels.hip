@@ -103,11 +103,11 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                                             unsigned long long* counters, const uint32_t* __restrict__ dcount) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (dcount) {
         const unsigned long long present = *dcount;
         n = present < n ? present : n;
     }
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
@@ -122,6 +122,35 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
     walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (active) finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
     if (COUNT) flush_counters(cnt, active, counters);
+}
+
+// pointInShadow's rays (main.cpp:104-135) for the shading wavefront: dist[i] = |fromPosToLight| of ray i.  The caller only
+// evaluates `hit && !(t + epsilon >= dist)`: the certified walk answers that question directly (WALK_OCCLUDED: bounded by
+// the light's distance, stops at the first qualifying triangle); a ray without certificate gets the exact closest hit.
+// hits[i] therefore holds a hit that decides the test like the reference's own, not necessarily the closest one.
+template <bool FAST>
+__global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ rays, const float* __restrict__ dist, unsigned long long n,
+                                       CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount) {
+    extern __shared__ uint32_t s_lds[];
+    if (dcount) {
+        const unsigned long long present = *dcount;
+        n = present < n ? present : n;
+    }
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    LaneCounters cnt;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    float t = 0.0f, qlen = 0.0f;
+    if (active) {
+        const float* r = rays + 7 * i;
+        o = f3(r[0], r[1], r[2]);
+        d = f3(r[3], r[4], r[5]);
+        t = r[6];
+        qlen = dist[i];
+    }
+    uint32_t hit_rec = REF_NONE;
+    walk_tree<false, FAST, WALK_OCCLUDED>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt, qlen);
+    if (active) finish_ray(S, o, d, t, hit_rec, hits + i, nullptr);
 }
 
 // Soft shadows of spherical lights (main.cpp:168-218): `samples` shadow rays per (hit item, light), generated in
@@ -154,7 +183,7 @@ __global__ CGRT_LB void k_soft_shadow(SceneDev S, SoftDev Q, const float* __rest
     const float lightT = t;
     uint32_t hit_rec = REF_NONE;
     LaneCounters cnt;
-    walk_tree<false, FAST, ANYHIT>(S, live, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
+    walk_tree<false, FAST, ANYHIT ? WALK_ANYHIT : WALK_CLOSEST>(S, live, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (live) {
         bool hit = hit_rec != REF_NONE;
         if (!ANYHIT || !hit) {  // spheres come after the meshes in BoundingVolumeHierarchy::intersect (bvh.cpp:875-880)
@@ -240,6 +269,17 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
         CGRT_LAUNCH2(k_trace_batch, true, fast, blocks, block, stream, S, rays, n, hits, normals, counters, dcount);
     else
         CGRT_LAUNCH2(k_trace_batch, false, fast, blocks, block, stream, S, rays, n, hits, normals, counters, dcount);
+    return hipGetLastError();
+}
+hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
+                               const uint32_t* dcount) {
+    if (n == 0) return hipSuccess;
+    const unsigned block = (unsigned)trace_block(S);
+    const unsigned blocks = grid_for(n, block);
+    if (S.fast_root != REF_NONE)
+        hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(block), lds_bytes(block), stream, S, rays, dist, n, hits, dcount);
+    else
+        hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(block), lds_bytes(block), stream, S, rays, dist, n, hits, dcount);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,

@@ -25,6 +25,19 @@
 
 namespace cgrt {
 
+// What the caller needs from the search:
+//   WALK_CLOSEST  the closest accepted triangle (BoundingVolumeHierarchy::intersect proper);
+//   WALK_ANYHIT   only the hit FLAG: the search stops at the first accepted triangle whose path is certified -- had the
+//                 reference accepted nothing, ray.t would still be the initial one and it would reach that leaf and accept it;
+//   WALK_OCCLUDED pointInShadow's question (main.cpp:104-135): is there a hit with `ray.t + epsilon < |fromPosToLight|`?
+//                 fl(t + eps) is monotone in t, so the reference answers yes iff its closest t qualifies, and ANY accepted
+//                 triangle T that qualifies AND whose path is certified settles it: the reference either accepts T or holds
+//                 a ray.t <= t_T by then, so its final t qualifies too.  No qualifying triangle anywhere -> the reference's
+//                 hit, if any, does not qualify either (it tests a subset): reported as a miss, which is what the caller's
+//                 test `hit && !(t + eps >= dist)` makes of it.  The search is bounded by the light's distance.
+enum { WALK_CLOSEST = 0, WALK_ANYHIT = 1, WALK_OCCLUDED = 2 };
+#define CGRT_SHADOW_EPS 0.001f  // main.cpp:110
+
 struct FastScan {
     float best_t;       // running minimum, starts at ray.t
     uint32_t best_rec;  // its record (REF_NONE: nothing accepted yet)
@@ -32,8 +45,9 @@ struct FastScan {
     bool onp;           // an origin-on-plane acceptance was seen (sticky)
 };
 
-__device__ __forceinline__ void fast_apply(const TriEval& E, const uint32_t rec, FastScan& F) {
-    const bool valid = !E.onp && E.den_ok && !(E.tt < 0) && E.inside;
+template <int MODE>
+__device__ __forceinline__ void fast_apply(const TriEval& E, const uint32_t rec, const float qlen, FastScan& F) {
+    const bool valid = !E.onp && E.den_ok && !(E.tt < 0) && E.inside && (MODE != WALK_OCCLUDED || !(E.tt + CGRT_SHADOW_EPS >= qlen));
     F.onp = F.onp || (E.onp && E.inside);
     const bool lt = valid && (E.tt < F.best_t);
     const bool eq = valid && (E.tt == F.best_t) && (F.best_rec != REF_NONE);  // equal to the INITIAL ray.t is a plain reject (:65)
@@ -43,9 +57,9 @@ __device__ __forceinline__ void fast_apply(const TriEval& E, const uint32_t rec,
 }
 
 // records [first, first + n): runs of the accelerators (1..2 by default) and small leaves without accelerator (<= 32)
-template <bool COUNT>
-__device__ __forceinline__ void fast_test_run(const SceneDev& S, const uint32_t first, const uint32_t n, const F3 o, const F3 d, FastScan& F,
-                                              LaneCounters& cnt) {
+template <bool COUNT, int MODE>
+__device__ __forceinline__ void fast_test_run(const SceneDev& S, const uint32_t first, const uint32_t n, const F3 o, const F3 d, const float qlen,
+                                              FastScan& F, LaneCounters& cnt) {
     if (COUNT) {
         cnt.tri += n;
         if (first_active_lane()) cnt.w_tri++;
@@ -57,10 +71,10 @@ __device__ __forceinline__ void fast_test_run(const SceneDev& S, const uint32_t 
         const float4 a1 = q[j], b1 = q[j + 1], c1 = q[j + 2], e1 = q[j + 3];
         const TriEval E0 = eval_record(a0, b0, c0, e0, o, d);
         const TriEval E1 = eval_record(a1, b1, c1, e1, o, d);
-        fast_apply(E0, first, F);
-        if (n > 1) fast_apply(E1, first + 1, F);
+        fast_apply<MODE>(E0, first, qlen, F);
+        if (n > 1) fast_apply<MODE>(E1, first + 1, qlen, F);
     } else {
-        for (uint32_t i = 0; i < n; i++) fast_apply(eval_record(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], o, d), first + i, F);
+        for (uint32_t i = 0; i < n; i++) fast_apply<MODE>(eval_record(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], o, d), first + i, qlen, F);
     }
 }
 
@@ -125,8 +139,8 @@ __device__ __forceinline__ void quad_merge(float& bt, uint32_t& br, bool& tie, c
 
 // live: lanes that carry an unfinished ray (<= 16 of them); their state is (F, cur, sp) with the stack in their own slice.
 // On return the owners hold their ray's final FastScan and `failed`.
-template <bool COUNT, bool ANYHIT>
-__device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long long live, const bool mine, const Walk& W, FastScan& F,
+template <bool COUNT, int MODE>
+__device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long long live, const bool mine, const Walk& W, const float qlen_own, FastScan& F,
                                           uint32_t cur, int sp, bool& failed, uint32_t* __restrict__ wave_stk, uint32_t* __restrict__ s_map,
                                           LaneCounters& cnt) {
     const int lane = threadIdx.x & 63;
@@ -155,6 +169,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
     P.regular = true;
     const F3 o = f3(__shfl(W.o.x, src, 64), __shfl(W.o.y, src, 64), __shfl(W.o.z, src, 64));
     const F3 d = f3(__shfl(W.d.x, src, 64), __shfl(W.d.y, src, 64), __shfl(W.d.z, src, 64));
+    const float qlen = (MODE == WALK_OCCLUDED) ? __shfl(qlen_own, src, 64) : 0.0f;
     QuadState G;
     G.best_t = __shfl(F.best_t, src, 64);
     G.best_rec = __shfl(F.best_rec, src, 64);
@@ -227,7 +242,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
             L.best_rec = G.best_rec;
             L.tie = G.tie;
             L.onp = false;
-            fast_test_run<COUNT>(S, run_first(ref), run_count(ref), o, d, L, cnt);
+            fast_test_run<COUNT, MODE>(S, run_first(ref), run_count(ref), o, d, qlen, L, cnt);
             lt = L.best_t;
             lr = L.best_rec;
             ltie = L.tie;
@@ -261,7 +276,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
         G.best_rec = lr;
         G.tie = ltie;
         G.onp = G.onp || lonp;
-        if (ANYHIT && (G.best_rec != REF_NONE || G.onp)) qsp = 0;
+        if (MODE != WALK_CLOSEST && (G.best_rec != REF_NONE || G.onp)) qsp = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round reads what the other lanes of the quad just wrote
     }
     // results back to the owners (quad `myrank`, any of its lanes)
@@ -280,18 +295,16 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
 
 // The certified search for a whole wave.  `alive`: the lane carries a ray that passed the root gate, lies inside both
 // envelopes (W.P.regular, W.R.fd) and wants the certified walk; the other lanes only help in the quad tail.  Must be called
-// by all 64 lanes (wave-uniform control flow).  Returns, per alive lane, true when (W.t, W.hit_rec) now hold the reference's
-// result; false: W is untouched, take the exact walk.
-// ANYHIT (the caller only needs the hit FLAG): the search stops at the first accepted triangle; if that triangle's path is
-// certified the reference's flag is set too -- had the reference accepted nothing, ray.t would still be the initial one and
-// it would reach that leaf and accept the triangle.
-template <bool COUNT, bool ANYHIT>
-__device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool alive, Walk& W, uint32_t* __restrict__ wave_stk,
+// by all 64 lanes (wave-uniform control flow).  Returns, per alive lane, true when (W.t, W.hit_rec) now hold the answer the
+// MODE asks for (see WALK_*); false: W is untouched, take the exact walk.  qlen: WALK_OCCLUDED's |fromPosToLight|.
+template <bool COUNT, int MODE>
+__device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool alive, Walk& W, const float qlen, uint32_t* __restrict__ wave_stk,
                                                uint32_t* __restrict__ s_map, LaneCounters& cnt) {
     uint32_t* __restrict__ stk = wave_stk + (threadIdx.x & 63u);
     const F3 o = W.o, d = W.d;
     FastScan F;
-    F.best_t = W.t;
+    // the search bound: ray.t, and for an occlusion query the light's distance (t + eps < qlen needs t < qlen)
+    F.best_t = (MODE == WALK_OCCLUDED) ? fminf(W.t, qlen) : W.t;
     F.best_rec = REF_NONE;
     F.tie = false;
     F.onp = false;
@@ -302,16 +315,16 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
         const unsigned long long live = __ballot(!done);
         if (live == 0ull) break;
         if (CGRT_QUAD_TAIL_RAYS > 0 && __popcll(live) <= CGRT_QUAD_TAIL_RAYS) {
-            quad_tail<COUNT, ANYHIT>(S, live, !done, W, F, cur, sp, failed, wave_stk, s_map, cnt);
+            quad_tail<COUNT, MODE>(S, live, !done, W, qlen, F, cur, sp, failed, wave_stk, s_map, cnt);
             break;
         }
         if (!done) {
             if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
             if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
             if (cur != REF_NONE && (cur & REF_LEAF)) {
-                fast_test_run<COUNT>(S, run_first(cur), run_count(cur), o, d, F, cnt);
+                fast_test_run<COUNT, MODE>(S, run_first(cur), run_count(cur), o, d, qlen, F, cnt);
                 cur = REF_NONE;
-                if (ANYHIT && (F.best_rec != REF_NONE || F.onp)) done = true;
+                if (MODE != WALK_CLOSEST && (F.best_rec != REF_NONE || F.onp)) done = true;
             }
             if (cur == REF_NONE && !done) {
                 if (sp > 0) {
@@ -323,7 +336,7 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
             }
         }
     }
-    if (!alive || failed || F.onp || F.tie) return false;
+    if (!alive || failed || F.onp || (MODE == WALK_CLOSEST && F.tie)) return false;  // (a tie changes the record, not the flag)
     if (F.best_rec != REF_NONE) {
         if (!path_certified<COUNT>(S, W, F.best_rec, F.best_t, cnt)) return false;
         W.t = F.best_t;
@@ -333,14 +346,17 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
 }
 
 // BoundingVolumeHierarchy::intersect's mesh part (bvh.cpp:870-875) for the rays of a wave (one per `active` lane; call
-// with all 64 lanes; wave_stk / s_map: CGRT_WAVE_STACK / CGRT_WAVE_MAP of the kernel's dynamic LDS): root gate, then the certified walk when the scene has a fast tree and the ray lies inside both
-// envelopes (RayPre::regular, RayFast::fd), the exact walk otherwise or when no certificate was obtained.
-// ANYHIT (exact walk): stop after the first leaf that accepted a triangle.  The walk up to there is the reference's, so the
-// hit FLAG is the reference's (some acceptance happens upstream iff one happens in the first leaf that has one); t and the
-// record are those of that leaf, not the final ones.
-template <bool COUNT, bool FAST, bool ANYHIT = false>
+// with all 64 lanes; wave_stk / s_map: CGRT_WAVE_STACK / CGRT_WAVE_MAP of the kernel's dynamic LDS): root gate, then the
+// certified walk when the scene has a fast tree and the ray lies inside both envelopes (RayPre::regular, RayFast::fd), the
+// exact walk otherwise or when no certificate was obtained.
+// MODE (see WALK_*): the exact walk answers WALK_ANYHIT by stopping after the first leaf that accepted a triangle -- the walk
+// up to there is the reference's, so the hit FLAG is the reference's (some acceptance happens upstream iff one happens in
+// the first leaf that has one); t and the record are those of that leaf, not the final ones -- and WALK_OCCLUDED with the
+// full closest hit.
+template <bool COUNT, bool FAST, int MODE = WALK_CLOSEST>
 __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
-                                          uint32_t* __restrict__ wave_stk, uint32_t* __restrict__ s_map, LaneCounters& cnt) {
+                                          uint32_t* __restrict__ wave_stk, uint32_t* __restrict__ s_map, LaneCounters& cnt,
+                                          const float qlen = 0.0f) {
     Walk W;
     W.o = o;
     W.d = d;
@@ -351,7 +367,7 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, 
     bool certified = false;
     if (FAST) {
         const bool eligible = entered && W.P.regular && W.R.fd;
-        if (__any(eligible)) certified = walk_fast_wave<COUNT, ANYHIT>(S, eligible, W, wave_stk, s_map, cnt);
+        if (__any(eligible)) certified = walk_fast_wave<COUNT, MODE>(S, eligible, W, qlen, wave_stk, s_map, cnt);
         if (COUNT && eligible && !certified) cnt.fallback++;
     }
     if (entered && !certified) {
@@ -359,7 +375,7 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, 
             W.P = make_raypre(S, W.o, W.d, W.t);
             W.R = make_rayfast(S, W.o, W.d);
         }
-        walk_tree_unified<COUNT, ANYHIT>(S, W, wave_stk + (threadIdx.x & 63u), cnt);
+        walk_tree_unified<COUNT, MODE == WALK_ANYHIT>(S, W, wave_stk + (threadIdx.x & 63u), cnt);
     }
     t = W.t;
     hit_rec = W.hit_rec;
