@@ -280,6 +280,28 @@ struct SubBuilder {
     }
 };
 
+// Can the reference accept this triangle only at a point of its own box (up to rounding)?  That is what lets the kernels
+// skip a triangle whose widened box the ray misses.  It holds whenever the stored plane normal n = normalize(cross(e1, e2))
+// (ray_tracing.cpp:74-82, float) is a finite non-zero vector along the true normal.  It fails when the float arithmetic
+// degenerates: |cross|^2 overflows -> 1/sqrt(inf) = 0 -> n = (0, 0, 0), D = 0, and then `dot(o, n) == D` holds for EVERY ray
+// (the origin-on-plane rule, :43-47, accepts it at t = 0 wherever the ray is); |cross|^2 underflows -> n = +-inf / NaN with
+// inf == inf comparisons; a cross product so small that its components are subnormal points anywhere.  Such "wild" triangles
+// must be tested by every ray that reaches their leaf: a leaf that holds one is scanned linearly, and the scene gets no fast
+// tree (tests/test_adversarial_gpu.py scales a scene until this happens).
+static bool plane_is_tame(const float* a, const float* b, const float* c, const F3 n) {
+    // a NaN component (zero-area triangle: 0 * inf) makes every dot product with n NaN: no comparison succeeds, the triangle
+    // is never accepted -- inert, and skipping it is always right
+    if (n.x != n.x || n.y != n.y || n.z != n.z) return true;
+    if (!(std::fabs(n.x) <= 4.0f && std::fabs(n.y) <= 4.0f && std::fabs(n.z) <= 4.0f)) return false;  // +-inf
+    const double e1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]};
+    const double e2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+    const double cx = e1[1] * e2[2] - e2[1] * e1[2], cy = e1[2] * e2[0] - e2[2] * e1[0], cz = e1[0] * e2[1] - e2[0] * e1[1];
+    const double len2 = cx * cx + cy * cy + cz * cz, n2 = (double)n.x * n.x + (double)n.y * n.y + (double)n.z * n.z;
+    if (!(n2 >= 0.25 && n2 <= 4.0)) return false;              // (0, 0, 0) from an overflowed length, or a length that lost its precision
+    if (!(len2 >= 0x1p-200 && len2 <= 0x1p+200)) return false;  // |cross| in [2^-100, 2^100]: its float components carry full precision
+    return true;
+}
+
 // The leaves are independent: contiguous ranges of them are built on worker threads into private node arrays, which are
 // then concatenated in leaf order -- the result is the array a single thread would have produced, node for node.
 void build_leaf_accelerators(BuiltBvh& out, int leaf_tris) {
@@ -292,7 +314,8 @@ void build_leaf_accelerators(BuiltBvh& out, int leaf_tris) {
     auto work = [&](unsigned t) {
         SubBuilder sb{out.tris, out.tri_normals, part[t], lt, {}, {}, {}, {}};  // leaves own disjoint record ranges
         const size_t b = nleaves * t / nthreads, e = nleaves * (t + 1) / nthreads;
-        for (size_t i = b; i < e; i++) sb.run(out.leaves[i]);
+        for (size_t i = b; i < e; i++)
+            if (!out.leaf_wild[i]) sb.run(out.leaves[i]);  // a leaf with a wild triangle keeps the reference's linear scan
     };
     if (nthreads == 1) {
         work(0);
@@ -450,7 +473,7 @@ void build_fast_tree(BuiltBvh& out, bool force, int open) {
     out.paths.clear();
     out.tri_leaf.clear();
     const size_t nleaves = out.leaves.size();
-    if (SUB_WIDTH != 4 || nleaves == 0 || !out.geometry_finite) return;
+    if (SUB_WIDTH != 4 || nleaves == 0 || !out.geometry_finite || out.has_wild) return;
     if (!force && out.subnodes.empty()) return;  // no fat leaves: the reference tree already ends in single triangles
     std::vector<Box6> box(nleaves);
     std::vector<uint32_t> ref(nleaves);
@@ -687,6 +710,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
     out.leaves.resize(nlf);
     out.tris.resize(sc.ntris);
     out.tri_normals.resize(sc.ntris);
+    out.leaf_wild.assign(nlf, 0);
     auto ref_of = [&](int node) -> uint32_t {
         return out.nodes[node].leaf ? (REF_LEAF | (uint32_t)out.node_to_ref_index[node]) : (uint32_t)out.node_to_ref_index[node];
     };
@@ -718,6 +742,10 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
                 T.prim_id = p;
                 T.mesh_id = sc.tri_mesh[p];
                 T.scan_k = k;
+                if (!plane_is_tame(a, b, c, pn)) {
+                    out.leaf_wild[out.node_to_ref_index[i]] = 1;
+                    out.has_wild = true;
+                }
                 TriNormals& N = out.tri_normals[w];
                 std::memcpy(N.n1, a + 3, 12);
                 std::memcpy(N.n2, b + 3, 12);

@@ -41,6 +41,8 @@ struct BuiltBvh {
     std::vector<SubNode> subnodes;       // in-leaf accelerators of all leaves (empty when disabled)
     float scene_absmax = 0;              // largest |vertex coordinate|
     bool geometry_finite = true;         // no NaN / infinite vertex coordinate
+    bool has_wild = false;               // some triangle's float plane is degenerate (bvh_builder.cpp plane_is_tame)
+    std::vector<uint8_t> leaf_wild;      // per leaf: holds such a triangle -> no accelerator, linear scan
     // certified walk (walk_fast.h): 4-wide tree over the leaves (its nodes are appended to `subnodes`), per-leaf box paths,
     // leaf of every record; fast_root == REF_NONE when the scene has none
     uint32_t fast_root = REF_NONE;

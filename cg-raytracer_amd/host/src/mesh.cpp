@@ -87,17 +87,30 @@ std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNorm
         } else if (k == "f") {
             std::vector<Corner> face;
             std::string tok;
+            // An index that is not a number, is 0, or points outside the vertices / normals read so far makes the file
+            // invalid: upstream's importer refuses it ("Assimp failed to load mesh file", mesh.cpp:66-71) and throws.
+            auto index = [&](const std::string& t, size_t count) -> int {
+                size_t used = 0;
+                long v = 0;
+                try {
+                    v = std::stol(t, &used);
+                } catch (const std::exception&) {
+                    used = 0;
+                }
+                const long idx = v > 0 ? v - 1 : (long)count + v;
+                if (used != t.size() || v == 0 || idx < 0 || idx >= (long)count) {
+                    std::cerr << "Assimp failed to load mesh file " << file << std::endl;
+                    throw std::exception();
+                }
+                return (int)idx;
+            };
             while (ss >> tok) {
                 Corner c{0, -1};
                 const size_t s1 = tok.find('/');
-                c.v = std::stoi(tok.substr(0, s1));
-                c.v = c.v > 0 ? c.v - 1 : (int)V.size() + c.v;
+                c.v = index(tok.substr(0, s1), V.size());
                 if (s1 != std::string::npos) {
                     const size_t s2 = tok.find('/', s1 + 1);
-                    if (s2 != std::string::npos && s2 + 1 < tok.size()) {
-                        c.n = std::stoi(tok.substr(s2 + 1));
-                        c.n = c.n > 0 ? c.n - 1 : (int)N.size() + c.n;
-                    }
+                    if (s2 != std::string::npos && s2 + 1 < tok.size()) c.n = index(tok.substr(s2 + 1), N.size());
                 }
                 face.push_back(c);
             }
