@@ -327,6 +327,10 @@ def main():
                 best = st
         wall = time.perf_counter() - t_start
         rays = best["primary_rays"] + best["shadow_rays"] + best["reflection_rays"]
+        _, _, work = scene.render_counted(cam, W, H, max_level=2)  # instrumented frame, outside the timed region
+        parts = {k: algorithmic_bytes(v, rs) for k, v in work.items()}
+        alg_bytes = sum(parts.values())
+        achieved = alg_bytes / (best["device_ms"] * 1e-3) / 1e9
         out = {
             "metric": f"rays/sec of the whole shaded frame (primary + shadow + mirror, depth 2, {scene_name} @{W}x{H})",
             "value": round(rays / (best["device_ms"] * 1e-3) / 1e6, 3),
@@ -343,6 +347,23 @@ def main():
                                    f"{best['shadow_rays']} shadow, {best['reflection_rays']} mirror rays",
                        "timing": "ms_per_step: HIP events around all kernels of the best frame (device side of cgrt_render); "
                                  f"host-inclusive mean {wall / args.steps * 1e3:.3f} ms (RGB download included)"},
+            "roofline": {
+                "bound": "hbm",
+                "bound_note": "classification of SURVEY.md 8(d); like the primary kernel these batches are latency-bound (their time is the time of their hardest rays), see profiles/",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "all traversal kernels of the frame (k_trace_primary_compact, k_trace_shadow, k_trace_batch) over the frame's device time, shading kernels included in the time",
+                "kernel_ms": round(best["device_ms"], 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "algorithmic_bytes_by_ray_kind": {k: int(v) for k, v in parts.items()},
+                "per_ray_entering_tree": {kind: {k: round(v[k] / max(1, v["tree_rays"]), 2) for k in ("inner_visits", "tri_tests", "sub_visits", "cert_boxes")}
+                                          for kind, v in work.items()},
+                "rays_entering_tree": {kind: v["tree_rays"] for kind, v in work.items()},
+                "fallback_rays": {kind: v["fallback_rays"] for kind, v in work.items()},
+            },
         }
     if rank == 0 and out is not None:
         if world == 1 and args.workload == "primary" and not args.no_extras and scaling == "headline" and not args.obj and not (args.width and args.height):

@@ -108,7 +108,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
 ]  # fmt: skip
@@ -154,6 +154,7 @@ def lib() -> C.CDLL:
     L.cgrt_trace_primary_device.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp, vp]
     L.cgrt_generate_rays.argtypes = [vp, C.POINTER(Camera)] + [i32] * 6 + [vp]
     L.cgrt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats)]
+    L.cgrt_render_counted.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats), C.POINTER(Counters)]
     L.cgrt_render_soft.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, vp, C.POINTER(RenderStats)]
     L.cgrt_render_rank.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, i32, i32, vp, C.POINTER(RenderStats)]
     L.cgrt_trace_primary_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(Camera), i32, i32, vp, vp, C.POINTER(MultiStats)]
@@ -363,6 +364,16 @@ class Scene:
         c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
         _check(lib().cgrt_render(self._h, C.byref(c), W, H, _ptr(lights), len(lights), max_level, _ptr(rgb), C.byref(st)))
         return rgb, {k: getattr(st, k) for k, _ in st._fields_}
+
+    def render_counted(self, cam, W: int, H: int, lights=None, max_level: int = 2):
+        """cgrt_render_counted: (rgb, stats, {"primary" / "shadow" / "mirror": counters dict}) of an instrumented frame."""
+        lights = _f32(self.sd.point_lights if lights is None else lights, (-1, 6))
+        rgb = np.zeros((W * H, 3), np.float32)
+        st = RenderStats()
+        work = (Counters * 3)()
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_render_counted(self._h, C.byref(c), W, H, _ptr(lights), len(lights), max_level, _ptr(rgb), C.byref(st), work))
+        return rgb, {k: getattr(st, k) for k, _ in st._fields_}, dict(zip(("primary", "shadow", "mirror"), (w.as_dict() for w in work)))
 
     def render_soft(self, cam, W: int, H: int, spherical, units, samples: int = 200, seed: int = 0, lights=None, max_level: int = 2,
                     closest_hit: bool = False):

@@ -93,7 +93,7 @@ struct Builder {
 // the earlier scan position, and an origin-on-plane acceptance (t = 0, ray_tracing.cpp:43-47) goes to
 // the LAST such triangle.  So the kernel may test the triangles in any order -- and skip any triangle
 // that provably cannot be accepted -- as long as it applies that rule.  This builds, per reference
-// leaf, a 4-wide (or binary, CGRT_SUB_WIDTH) BVH (surface-area heuristic, full sweep on every axis) used only to skip triangles
+// leaf, a 4-wide BVH (surface-area heuristic, full sweep on every axis) used only to skip triangles
 // whose padded box the ray misses or enters beyond the current best t.  The reference topology, its
 // visit order and its culling decisions above the leaves are untouched.
 //
@@ -183,7 +183,7 @@ struct SubBuilder {
         const uint32_t cn = e - b;
         // a child becomes a run of records when it is small enough or no depth is left
         if (cn <= (uint32_t)leaf_tris || depth_left <= 0) return REF_LEAF | ((cn - 1) << 26) | (base + b);
-        return SUB_WIDTH == 4 ? build4(base, b, e, depth_left) : build(base, b, e, depth_left);
+        return build4(base, b, e, depth_left);
     }
 
     // 4-wide node over idx[b, e) (more than leaf_tris triangles): split in two, then each half again; the node is two
@@ -228,22 +228,6 @@ struct SubBuilder {
         return me;
     }
 
-    // Binary node over idx[b, e) (more than leaf_tris triangles); returns its node index.
-    uint32_t build(uint32_t base, uint32_t b, uint32_t e, int depth_left) {
-        const uint32_t me = (uint32_t)nodes.size();
-        nodes.push_back(SubNode());
-        const uint32_t m = split(b, e, capacity(depth_left - 1, leaf_tris));
-        const Box6 lb = range_box(b, m), rb = range_box(m, e);
-        const uint32_t ref[2] = {child_ref(base, b, m, depth_left - 1), child_ref(base, m, e, depth_left - 1)};
-        SubNode& N = nodes[me];
-        std::memcpy(N.box0, &lb, 24);
-        std::memcpy(N.box1, &rb, 24);
-        N.ref0 = ref[0];
-        N.ref1 = ref[1];
-        N.pad[0] = N.pad[1] = 0;
-        return me;
-    }
-
     void run(LeafRec& L) {
         const uint32_t n = L.count;
         if (n <= (uint32_t)leaf_tris) return;  // small leaf: all candidates are tested
@@ -266,7 +250,7 @@ struct SubBuilder {
             }
             idx[i] = i;
         }
-        L.sub_root = SUB_WIDTH == 4 ? build4(L.first, 0, n, SUB_MAX_DEPTH) : build(L.first, 0, n, SUB_MAX_DEPTH);
+        L.sub_root = build4(L.first, 0, n, SUB_MAX_DEPTH);
         leaf_tris = saved;
         // apply the permutation to the records (scan_k keeps every triangle's reference scan position)
         std::vector<TriRecord> t2(n);
@@ -473,7 +457,7 @@ void build_fast_tree(BuiltBvh& out, bool force, int open) {
     out.paths.clear();
     out.tri_leaf.clear();
     const size_t nleaves = out.leaves.size();
-    if (SUB_WIDTH != 4 || nleaves == 0 || !out.geometry_finite || out.has_wild) return;
+    if (nleaves == 0 || !out.geometry_finite || out.has_wild) return;
     if (!force && out.subnodes.empty()) return;  // no fat leaves: the reference tree already ends in single triangles
     std::vector<Box6> box(nleaves);
     std::vector<uint32_t> ref(nleaves);
@@ -770,7 +754,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
     if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
     if (opt.fast_tree != 0) build_fast_tree(out, opt.fast_tree > 0, opt.fast_open);
     // one 64-byte record array on the device: [packets | subnodes | tris]; make sub/tri references global
-    if (SUB_WIDTH == 4 && (out.packets.size() & 1u)) {
+    if (out.packets.size() & 1u) {
         NodePacket pad;  // keeps every 128-byte accelerator node inside one 128-byte line (the array is 256-byte aligned)
         std::memset(&pad, 0, sizeof(pad));
         out.packets.push_back(pad);
@@ -794,7 +778,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
     if (out.fast_root != REF_NONE) out.fast_root += (out.fast_root & REF_LEAF) ? out.tri_base : out.sub_base;
     out.root_box = out.nodes[0].box;
     out.root_ref = ref_of(0);
-    if (SUB_WIDTH == 4 && !out.subnodes.empty()) {
+    if (!out.subnodes.empty()) {
         // accelerated leaves are referenced by their accelerator root (cgrt_layout.h REF_LEAF_ACCEL)
         auto direct = [&](uint32_t r) -> uint32_t {
             if (r == REF_NONE || !(r & REF_LEAF)) return r;

@@ -177,7 +177,7 @@ struct CgrtScene {
     struct WorkSlot {
         void* p = nullptr;
         size_t cap = 0;
-    } work[24];
+    } work[24];  // slots 0..20 are in use (render_impl)
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
@@ -429,13 +429,13 @@ int cgrt_debug_check_layout(CgrtScene* s) {
         uint32_t li;
         if (r & REF_LEAF_ACCEL) {
             const uint32_t root = r & REF_INDEX26;
-            if (SUB_WIDTH != 4 || root < B.sub_base || root >= B.tri_base || ((root - B.sub_base) & 1u)) return false;
+            if (root < B.sub_base || root >= B.tri_base || ((root - B.sub_base) & 1u)) return false;
             li = B.subnodes[root - B.sub_base].pad[0];
             if (li >= nleaf || B.leaves[li].sub_root != root) return false;
         } else {
             li = r & ~REF_LEAF;
             if (li >= nleaf) return false;
-            if (SUB_WIDTH == 4 && B.leaves[li].sub_root != REF_NONE) return false;  // an accelerated leaf must be referenced directly
+            if (B.leaves[li].sub_root != REF_NONE) return false;  // an accelerated leaf must be referenced directly
         }
         if (leaf_seen[li]) return false;  // a tree: every leaf has one parent
         leaf_seen[li] = 1;
@@ -470,8 +470,8 @@ int cgrt_debug_check_layout(CgrtScene* s) {
                 continue;
             }
             if (r < B.sub_base || r >= B.tri_base) return fail(CGRT_E_ARG, "accelerator node reference out of range");
-            const uint32_t width_recs = SUB_WIDTH == 4 ? 2u : 1u;
-            if (SUB_WIDTH == 4 && ((r - B.sub_base) & 1u)) return fail(CGRT_E_ARG, "4-wide node not 128-byte aligned");
+            const uint32_t width_recs = 2u;
+            if ((r - B.sub_base) & 1u) return fail(CGRT_E_ARG, "4-wide node not 128-byte aligned");
             for (uint32_t h = 0; h < width_recs; h++) {
                 const SubNode& N = B.subnodes[r - B.sub_base + h];
                 todo.push_back(N.ref0);
@@ -525,7 +525,7 @@ int cgrt_debug_check_layout(CgrtScene* s) {
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes) {
     if (node_bytes) *node_bytes = sizeof(NodePacket);
     if (tri_bytes) *tri_bytes = sizeof(TriRecord);
-    if (sub_bytes) *sub_bytes = sizeof(SubNode) * (SUB_WIDTH == 4 ? 2 : 1);  // bytes read per accelerator node visit
+    if (sub_bytes) *sub_bytes = sizeof(SubNode) * 2;  // bytes read per accelerator node visit
     if (hit_bytes) *hit_bytes = sizeof(CgrtHit);
 }
 
@@ -835,8 +835,10 @@ int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters
 
 // ------------------------------------------------------------------------------------------------
 // renderRayTracing / getFinalColor (src/main.cpp:298-310, :648-720) as a device wavefront
+// counted (optional, 3 blocks): the frame is rendered with the instrumented kernels (never timed) and the work of its primary,
+// shadow and mirror traversals is returned separately
 static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
-                       int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats) {
+                       int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats, CgrtCounters* counted = nullptr) {
     if (!s || !cam || !rgb || (nlights && !lights)) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     if (W <= 0 || H <= 0 || max_level < 0 || max_level > 16) return fail(CGRT_E_ARG, "bad frame size or recursion depth");
@@ -860,7 +862,15 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     // traversed on a second stream while the level itself is still being shaded).
     WsBuf rays[2] = {{s, 0}, {s, 1}}, hits[2] = {{s, 2}, {s, 3}}, normals[2] = {{s, 4}, {s, 5}}, pix[2] = {{s, 6}, {s, 7}}, ipix{s, 8},
           srays{s, 9}, shits{s, 10}, sdist{s, 11}, sslot{s, 12}, dlights{s, 13}, levels{s, 14}, drgb{s, 15}, dctr{s, 16}, dslights{s, 17},
-          dunits{s, 18}, dlit{s, 19};
+          dunits{s, 18}, dlit{s, 19}, dwork{s, 20};
+    unsigned long long *cw_primary = nullptr, *cw_shadow = nullptr, *cw_mirror = nullptr;
+    if (counted) {
+        HIP_TRY(dwork.alloc(3 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(dwork.p, 0, 3 * 8 * sizeof(unsigned long long)));
+        cw_primary = dwork.as<unsigned long long>();
+        cw_shadow = cw_primary + 8;
+        cw_mirror = cw_primary + 16;
+    }
     HIP_TRY(ipix.alloc(n * 4));  // pixels of level 0, kept to the end
     for (int k = 0; k < 2; k++) {
         HIP_TRY(rays[k].alloc(n * 28));
@@ -918,7 +928,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         // black, main.cpp:293, and spawn nothing)
         uint32_t* const primary_hits = dctr.as<uint32_t>() + 4 * (size_t)max_level + 3;
         HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(),
-                                             ipix.as<int>(), primary_hits, nullptr));
+                                             ipix.as<int>(), primary_hits, nullptr, cw_primary));
         st.primary_rays = owned_pixels(F);
         uint32_t nhit0 = 0;
         HIP_TRY(hipMemcpy(&nhit0, primary_hits, sizeof(nhit0), hipMemcpyDeviceToHost));
@@ -940,12 +950,12 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             if (overlap) {
                 HIP_TRY(hipEventRecord(aux.spawned, nullptr));
                 HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
-                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cnt, hits[b].as<CgrtHitDev>(), normals[b].as<float>(), nullptr, aux.s,
+                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cnt, hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, aux.s,
                                            ctr + 1));
                 HIP_TRY(hipEventRecord(aux.traced, aux.s));
             }
             if (L)
-                HIP_TRY(launch_trace_shadow(s->dev, srays.as<float>(), sdist.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, ctr + 0));
+                HIP_TRY(launch_trace_shadow(s->dev, srays.as<float>(), sdist.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, ctr + 0, cw_shadow));
             if (SL) {
                 Q.level = (uint32_t)level;
                 HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));
@@ -965,7 +975,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             st.soft_shadow_rays += (uint64_t)h[2] * SL * Q.samples;
             if (!spawn || h[1] == 0) break;
             if (!overlap)
-                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), h[1], hits[b].as<CgrtHitDev>(), normals[b].as<float>(), nullptr, nullptr));
+                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), h[1], hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, nullptr));
             cnt = h[1];
         }
     }
@@ -986,6 +996,14 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     st.device_ms = ms;
     st.levels = nlev;
     HIP_TRY(hipMemcpy(rgb, drgb.p, npix * 12, hipMemcpyDeviceToHost));
+    if (counted) {
+        unsigned long long h[24];
+        HIP_TRY(hipMemcpy(h, dwork.p, sizeof(h), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; k++) {
+            const unsigned long long* q = h + 8 * k;
+            counted[k] = CgrtCounters{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+        }
+    }
     if (stats) *stats = st;
     return CGRT_OK;
 }
@@ -993,6 +1011,11 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
 int cgrt_render(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level, float* rgb,
                 CgrtRenderStats* stats) {
     return render_impl(s, cam, W, H, lights, nlights, nullptr, max_level, 0, 1, rgb, stats);
+}
+int cgrt_render_counted(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, int max_level, float* rgb,
+                        CgrtRenderStats* stats, CgrtCounters* work3) {
+    if (!work3) return fail(CGRT_E_ARG, "work3 is NULL");
+    return render_impl(s, cam, W, H, lights, nlights, nullptr, max_level, 0, 1, rgb, stats, work3);
 }
 int cgrt_render_soft(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
                      int max_level, float* rgb, CgrtRenderStats* stats) {

@@ -37,8 +37,8 @@ struct LeafRec {
 };
 static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
 
-// One node of a leaf's in-leaf accelerator (a binary BVH over the triangles of ONE reference leaf,
-// DESIGN.md "In-leaf accelerator"), both child boxes inline (64 B).  A child is another SubNode
+// Half a node of a leaf's in-leaf accelerator or of the fast tree (DESIGN.md "In-leaf accelerator", "Certified walk"): two
+// child boxes inline (64 B); a node is two consecutive SubNodes, 128-byte aligned.  A child is another SubNode
 // (ref = index) or a run of 1..32 TriRecords (ref = REF_LEAF | (count - 1) << 26 | first record).
 struct alignas(16) SubNode {
     float box0[6];
@@ -49,15 +49,12 @@ struct alignas(16) SubNode {
 static const uint32_t SUB_RUN_MAX = 32;            // records per run
 static const uint32_t SUB_MAX_RECORDS = 1u << 26;  // run references address records with 26 bits
 static_assert(sizeof(SubNode) == 64, "SubNode must be 64 B");
-// Width of the in-leaf accelerator: 4 = every node is TWO consecutive SubNode records (four child boxes, half the
-// dependent steps of a binary tree; the frame is bounded by the dependent chain of its hardest rays), 2 = binary.
-#ifndef CGRT_SUB_WIDTH
-#define CGRT_SUB_WIDTH 4
-#endif
+// The in-leaf accelerator is 4 wide: every node is TWO consecutive SubNode records (four child boxes: half the dependent
+// steps of a binary tree; measured +10 %, profiles/r1_exp_accelerator_width.txt).
+static const int SUB_WIDTH = 4;
 #ifndef CGRT_SUB_MAX_DEPTH
-#define CGRT_SUB_MAX_DEPTH (CGRT_SUB_WIDTH == 4 ? 5 : 8)
+#define CGRT_SUB_MAX_DEPTH 5
 #endif
-static const int SUB_WIDTH = CGRT_SUB_WIDTH;
 static const int SUB_MAX_DEPTH = CGRT_SUB_MAX_DEPTH;               // levels of the accelerator under one reference leaf
 static const int SUB_STACK_ENTRIES = (SUB_WIDTH - 1) * SUB_MAX_DEPTH;  // a step defers at most WIDTH-1 children
 static const int SUB_LEAF_TRIS = 2;    // target triangles per run (1..4 measure within 3 % of each other on the dragon frame)
@@ -67,7 +64,7 @@ static const int SUB_LEAF_TRIS = 2;    // target triangles per run (1..4 measure
 static const int TOP_MAX_DEPTH = 6;
 static_assert((1 << (2 * TOP_MAX_DEPTH)) >= (1 << (MAX_LEVELS - 1)), "the top tree must hold every reference leaf");
 static const int FAST_STACK_ENTRIES = (SUB_WIDTH - 1) * (TOP_MAX_DEPTH + SUB_MAX_DEPTH);
-static_assert(SUB_WIDTH != 4 || FAST_STACK_ENTRIES <= 2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES, "the fast walk's stack must fit the exact walk's LDS slice");
+static_assert(FAST_STACK_ENTRIES <= 2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES, "the fast walk's stack must fit the exact walk's LDS slice");
 static const int PATH_BOXES = MAX_LEVELS - 1;  // boxes per leaf in SceneDev::paths (6 floats each)
 
 // One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent

@@ -42,7 +42,7 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
 hipError_t launch_brute_batch(const SceneDev& S, const float* rays, unsigned long long n, int mesh, CgrtHitDev* hits, float* normals, hipStream_t s);
 // pointInShadow's rays (main.cpp:104-135): hits[i] decides `hit && !(t + 0.001f >= dist[i])` like the reference's closest hit does
 hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
-                               const uint32_t* dcount = nullptr);
+                               const uint32_t* dcount = nullptr, unsigned long long* counters = nullptr);
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);
 // lit[item * nlights + l] += samples of spherical light l that reach it from item's hit point (zeroed by the caller)
 hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,
@@ -50,7 +50,7 @@ hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* 
 
 // primary frame for the shading wavefront: only the hits, appended to a compact list; count = one zeroed device word
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
-                                        int* pixels, uint32_t* count, hipStream_t stream);
+                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters = nullptr);
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream);
 // shading wavefront (shade_kernels.hip); every level is a compact list of live paths
 // counters: 3 device words {shadow rays appended, mirror rays appended, hits}, zeroed by the caller

@@ -38,9 +38,10 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
 // appended to a compact list {ray, hit, normal, pixel} (one atomic per workgroup, lanes ranked by ballot; workgroups
 // finish roughly in launch order, so the list keeps the frame's tile order).  Pixels that miss need no further work upstream
 // either (main.cpp:293: black).  count = one zeroed device word.
-template <bool FAST>
+template <bool COUNT, bool FAST>
 __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
-                                                float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count) {
+                                                float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count,
+                                                unsigned long long* counters) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
@@ -52,8 +53,9 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
     float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
     uint32_t hit_rec = REF_NONE;
-    walk_tree<false, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
+    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
     if (active) resolve_hit(S, o, d, t, hit_rec, true, h, nn);
+    if (COUNT) flush_counters(cnt, active, counters);
     // one atomic per workgroup (same-address atomics serialise at the L2); the workgroup's LDS is only released when its
     // last wave ends anyway, so waiting for it here costs no occupancy
     const bool keep = active && h.hit != 0;
@@ -128,9 +130,9 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
 // evaluates `hit && !(t + epsilon >= dist)`: the certified walk answers that question directly (WALK_OCCLUDED: bounded by
 // the light's distance, stops at the first qualifying triangle); a ray without certificate gets the exact closest hit.
 // hits[i] therefore holds a hit that decides the test like the reference's own, not necessarily the closest one.
-template <bool FAST>
+template <bool COUNT, bool FAST>
 __global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ rays, const float* __restrict__ dist, unsigned long long n,
-                                       CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount) {
+                                       CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount, unsigned long long* counters) {
     extern __shared__ uint32_t s_lds[];
     if (dcount) {
         const unsigned long long present = *dcount;
@@ -149,8 +151,9 @@ __global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ ray
         qlen = dist[i];
     }
     uint32_t hit_rec = REF_NONE;
-    walk_tree<false, FAST, WALK_OCCLUDED>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt, qlen);
+    walk_tree<COUNT, FAST, WALK_OCCLUDED>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt, qlen);
     if (active) finish_ray(S, o, d, t, hit_rec, hits + i, nullptr);
+    if (COUNT) flush_counters(cnt, active, counters);
 }
 
 // Soft shadows of spherical lights (main.cpp:168-218): `samples` shadow rays per (hit item, light), generated in
@@ -272,24 +275,26 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
     return hipGetLastError();
 }
 hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
-                               const uint32_t* dcount) {
+                               const uint32_t* dcount, unsigned long long* counters) {
     if (n == 0) return hipSuccess;
     const unsigned block = (unsigned)trace_block(S);
     const unsigned blocks = grid_for(n, block);
-    if (S.fast_root != REF_NONE)
-        hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(block), lds_bytes(block), stream, S, rays, dist, n, hits, dcount);
+    const bool fast = S.fast_root != REF_NONE;
+    if (counters)
+        CGRT_LAUNCH2(k_trace_shadow, true, fast, blocks, block, stream, S, rays, dist, n, hits, dcount, counters);
     else
-        hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(block), lds_bytes(block), stream, S, rays, dist, n, hits, dcount);
+        CGRT_LAUNCH2(k_trace_shadow, false, fast, blocks, block, stream, S, rays, dist, n, hits, dcount, counters);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
-                                        int* pixels, uint32_t* count, hipStream_t stream) {
+                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters) {
     if (F.nblocks == 0) return hipSuccess;
     const unsigned block = (unsigned)F.block;
-    if (S.fast_root != REF_NONE)
-        hipLaunchKernelGGL(k_trace_primary_compact<true>, dim3(F.nblocks), dim3(block), lds_bytes(block), stream, S, C, F, rays, hits, normals, pixels, count);
+    const bool fast = S.fast_root != REF_NONE;
+    if (counters)
+        CGRT_LAUNCH2(k_trace_primary_compact, true, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters);
     else
-        hipLaunchKernelGGL(k_trace_primary_compact<false>, dim3(F.nblocks), dim3(block), lds_bytes(block), stream, S, C, F, rays, hits, normals, pixels, count);
+        CGRT_LAUNCH2(k_trace_primary_compact, false, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters);
     return hipGetLastError();
 }
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream) {

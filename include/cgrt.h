@@ -208,6 +208,11 @@ int cgrt_render_soft(CgrtScene* scene, const CgrtCamera* cam, int W, int H, cons
 int cgrt_render_rank(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
                      const CgrtSoftShadows* soft, int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats);
 
+/* cgrt_render with the instrumented kernels (a separate, never timed frame): work3[0] / [1] / [2] receive the traversal work of
+ * the primary rays, of all shadow lists and of all mirror lists of the frame (SURVEY.md section 8(d) algorithmic bytes). */
+int cgrt_render_counted(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
+                        int max_level, float* rgb, CgrtRenderStats* stats, CgrtCounters* work3);
+
 /* One caller, N devices, ONE framebuffer (the reference's renderRayTracing fills one Screen,
  * main.cpp:648-720, its only parallel construct being rows of that frame, :653-656).  scenes[i] is a replica of the scene
  * created on its own device (cgrt_scene_create with different `device` arguments; the same device may repeat, every

@@ -221,3 +221,21 @@ def test_render_with_certified_walk(pkg, orc):
     assert rgb0.tobytes() == rgb1.tobytes()
     assert (st0["shadow_rays"], st0["reflection_rays"]) == (st1["shadow_rays"], st1["reflection_rays"])
     assert st1["shadow_rays"] > 0
+
+
+def test_counted_render_reports_the_secondary_work(pkg):
+    """cgrt_render_counted: same pixels as cgrt_render; the primary block equals cgrt_count_primary's, the shadow and mirror
+    blocks count exactly the rays the frame's statistics report."""
+    sd = pkg.scenes.make_dragon(30_000)
+    W, H = 160, 120
+    cam = pkg.scenes.default_camera(W, H)
+    sc = pkg.Scene(sd)
+    rgb, st = sc.render(cam, W, H, max_level=3)
+    rgb2, st2, work = sc.render_counted(cam, W, H, max_level=3)
+    assert rgb2.tobytes() == rgb.tobytes()
+    assert work["primary"]["rays"] == W * H == st2["primary_rays"]
+    assert work["shadow"]["rays"] == st2["shadow_rays"] > 0 and work["mirror"]["rays"] == st2["reflection_rays"] > 0
+    cp = sc.count_primary(cam, W, H)
+    for k in ("tree_rays", "sub_visits", "tri_tests", "cert_boxes", "fallback_rays"):
+        assert work["primary"][k] == cp[k]
+    assert work["shadow"]["tree_rays"] > 0 and work["mirror"]["sub_visits"] > 0
