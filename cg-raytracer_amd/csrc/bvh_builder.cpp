@@ -450,7 +450,7 @@ struct TopBuilder {
 
 // Called before the references are made global: everything is still in builder-local indices (subnode index, record
 // index), which the globalisation loop of build_reference_bvh then shifts like every other accelerator reference.
-void build_fast_tree(BuiltBvh& out, bool force, int open) {
+void build_fast_tree(BuiltBvh& out, bool force, bool leaf_accel, int open) {
     if (open < 0) open = 0;
     if (open > SUB_MAX_DEPTH) open = SUB_MAX_DEPTH;
     out.fast_root = REF_NONE;
@@ -458,7 +458,9 @@ void build_fast_tree(BuiltBvh& out, bool force, int open) {
     out.tri_leaf.clear();
     const size_t nleaves = out.leaves.size();
     if (nleaves == 0 || !out.geometry_finite || out.has_wild) return;
-    if (!force && out.subnodes.empty()) return;  // no fat leaves: the reference tree already ends in single triangles
+    // by default: not for scenes built without in-leaf accelerators (they are asked to scan leaves linearly) and not for a
+    // handful of triangles, where the exact walk's few steps are cheaper than a search plus a certificate
+    if (!force && (!leaf_accel || out.tris.size() < 16)) return;
     std::vector<Box6> box(nleaves);
     std::vector<uint32_t> ref(nleaves);
     for (size_t i = 0; i < out.nodes.size(); i++) {
@@ -752,7 +754,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
             if (!(c <= std::numeric_limits<float>::max())) out.geometry_finite = false;
         }
     if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
-    if (opt.fast_tree != 0) build_fast_tree(out, opt.fast_tree > 0, opt.fast_open);
+    if (opt.fast_tree != 0) build_fast_tree(out, opt.fast_tree > 0, opt.leaf_accel, opt.fast_open);
     // one 64-byte record array on the device: [packets | subnodes | tris]; make sub/tri references global
     if (out.packets.size() & 1u) {
         NodePacket pad;  // keeps every 128-byte accelerator node inside one 128-byte line (the array is 256-byte aligned)

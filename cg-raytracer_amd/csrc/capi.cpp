@@ -373,7 +373,7 @@ int cgrt_set_primary_mode(int mode) {
     return CGRT_OK;
 }
 int cgrt_set_fast_tree(int mode) {
-    if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (scenes with fat leaves), 0 (never) or 1 (whenever possible)");
+    if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (default policy), 0 (never) or 1 (whenever possible)");
     std::lock_guard<std::mutex> lk(g_options_mutex);
     g_build_options.fast_tree = mode;
     return CGRT_OK;

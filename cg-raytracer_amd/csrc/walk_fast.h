@@ -9,12 +9,14 @@
 //   (2) otherwise let T* be the triangle with the unique minimum t*.  The reference reaches T*'s leaf iff on the way
 //       down every node of the path is entered: origin strictly inside its box (startsInBox, bvh.cpp:647-661), or the
 //       box test (ray_tracing.cpp:162-200) passes with its parameter `cur` below the ray.t of that moment -- and, when
-//       the child was deferred, ray.t has not dropped below `cur` = tSecond by the time it is popped (:581-585).  ray.t >= t*
-//       throughout, so "cur < t*" at every node of the path implies all of that, whatever the walk met before; in the leaf
-//       T* is then accepted (t* < ray.t unless an equal-t triangle came first) and nothing later beats it.
+//       the child was deferred, ray.t has not dropped below `cur` = tSecond by the time it is popped (:581-585).  Until T* is
+//       accepted ray.t is the initial value or the t of some OTHER accepted triangle, all of them strictly above t* (the
+//       minimum is unique), so "cur <= t*" at every node of the path implies all of that, whatever the walk met before --
+//       including cur == t* exactly, the case of an axis-aligned face in its zero-thickness box; in the leaf T* is then
+//       accepted (t* < ray.t) and nothing later beats it.
 // The certificate is therefore: a strict unique minimum (any equal-t acceptance anywhere -> not certified), no
 // origin-on-plane acceptance anywhere (ray_tracing.cpp:43-47 has no t < ray.t guard: visit order decides), and
-// inside-or-(exact box test at t*) for the <= 11 boxes of T*'s path (SceneDev::paths) -- the reference's own arithmetic
+// inside-or-(exact box test with cur <= t*) for the <= 11 boxes of T*'s path (SceneDev::paths) -- the reference's own arithmetic
 // (ray_box_fast, exact quotients).  A ray that is not certified is simply walked by walk_tree_unified: the certified walk
 // can only be slower, never different.  F4's false misses fail a path box and take that route.
 //
@@ -32,7 +34,7 @@ namespace cgrt {
 //   WALK_OCCLUDED pointInShadow's question (main.cpp:104-135): is there a hit with `ray.t + epsilon < |fromPosToLight|`?
 //                 fl(t + eps) is monotone in t, so the reference answers yes iff its closest t qualifies, and ANY accepted
 //                 triangle T that qualifies AND whose path is certified settles it: the reference either accepts T or holds
-//                 a ray.t <= t_T by then, so its final t qualifies too.  No qualifying triangle anywhere -> the reference's
+//                 a ray.t <= t_T by then (a box culled with cur <= t_T means ray.t <= cur), so its final t qualifies too.  No qualifying triangle anywhere -> the reference's
 //                 hit, if any, does not qualify either (it tests a subset): reported as a miss, which is what the caller's
 //                 test `hit && !(t + eps >= dist)` makes of it.  The search is bounded by the light's distance.
 enum { WALK_CLOSEST = 0, WALK_ANYHIT = 1, WALK_OCCLUDED = 2 };
@@ -92,8 +94,10 @@ __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W,
         const float2 a = pb[3 * i], b = pb[3 * i + 1], c = pb[3 * i + 2];
         float tb;
         bool inside;
-        const bool hit = ray_box_fast<true>(f3(a.x, a.y, b.x), f3(b.y, c.x, c.y), W.o, W.d, R, t, tb, inside);
-        ok = ok && (hit || inside);
+        // the geometric part of the box test with the reference's arithmetic (t = +inf: no `cur >= ray.t` rejection), then
+        // cur <= t: see the header -- every ray.t the reference can hold before it accepts T is strictly above t
+        const bool geom = ray_box_fast<true>(f3(a.x, a.y, b.x), f3(b.y, c.x, c.y), W.o, W.d, R, __builtin_inff(), tb, inside);
+        ok = ok && (inside || (geom && !(tb > t)));
     }
     return ok;
 }

@@ -116,8 +116,9 @@ int cgrt_set_primary_mode(int mode);
  * tree with conservative tests, and its answer is kept only if a certificate holds -- unique strict minimum, no
  * origin-on-plane acceptance, and every box the reference tests on its way to that leaf is entered at the final t
  * (the reference's own box arithmetic); any other ray is walked exactly.  Results are identical either way (tested).
- *   cgrt_set_fast_tree: process-wide, for scenes created afterwards: -1 (default) = build it when the reference tree
- *     ends in fat leaves (an in-leaf accelerator exists), 0 = never, 1 = whenever the structures allow it.
+ *   cgrt_set_fast_tree: process-wide, for scenes created afterwards: -1 (default) = build it whenever the structures
+ *     allow it, except for scenes of fewer than 16 triangles and scenes created with the in-leaf accelerator off;
+ *     0 = never; 1 = whenever the structures allow it (finite geometry, tame float planes, every leaf accelerated or small).
  *   cgrt_scene_set_walk: per scene, 1 = certified walk (needs the fast tree: CGRT_E_ARG otherwise), 0 = exact walk only.
  *     Not to be changed while launches of the scene are being issued from other threads.
  *   cgrt_scene_walk: the current setting (1 / 0). */
