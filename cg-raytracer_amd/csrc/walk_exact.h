@@ -276,8 +276,13 @@ __device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P
         CGRT_CSWAP(k0, r0, k1, r1)
         CGRT_CSWAP(k2, r2, k3, r3)
         CGRT_CSWAP(k0, r0, k2, r2)
+#ifndef CGRT_SORT_FULL
+#define CGRT_SORT_FULL 1  // 0: only the nearest child is identified, the deferred ones keep their stored order
+#endif
+#if CGRT_SORT_FULL
         CGRT_CSWAP(k1, r1, k3, r3)
         CGRT_CSWAP(k1, r1, k2, r2)
+#endif
 #undef CGRT_CSWAP
         // Branch-free pushes: the slot is always written and only kept (sp advanced) when the child was hit; a
         // level defers at most three children, so the writes stay inside the lane's SUB_STACK_ENTRIES slots.

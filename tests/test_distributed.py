@@ -88,3 +88,36 @@ def test_frame_for_world_is_weak_scaling():
         assert abs(w * h / n - 1920 * 1080) / (1920 * 1080) < 0.01
         if per_rank:
             assert sum(per_rank) == w * h
+
+
+def test_config5_strong_scaling_split():
+    """BASELINE config 5 as bench.py --gpus N times it: ONE 3840x2160 frame, super-tile i to rank i % N.  For N = 1, 2, 4, 8
+    the ranks own disjoint sets whose union is the frame, and no rank is more than a few super-tiles away from its share."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+
+    entry.load_package()
+    from cg_raytracer_amd import tiling
+
+    W, H = 3840, 2160
+    for n in (1, 2, 4, 8):
+        owner = np.full((H, W), -1, np.int32)
+        counts = []
+        for r in range(n):
+            m = tiling.owned_mask(W, H, r, n)
+            assert (owner[m] == -1).all()
+            owner[m] = r
+            counts.append(int(m.sum()))
+            assert counts[-1] == tiling.owned_pixels(W, H, r, n)
+        assert (owner >= 0).all() and sum(counts) == W * H
+        assert max(counts) - min(counts) <= 8 * 64 * 64, counts  # shares differ by a few 64x64 super-tiles at most
+
+
+def test_bench_cli_documents_the_scaling_modes():
+    """bench.py's flags the driver and the docs rely on (no GPU needed for --help)."""
+    import subprocess
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--scaling", "--workload", "--obj", "--tris", "--walk"):
+        assert flag in out.stdout

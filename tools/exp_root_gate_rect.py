@@ -1,7 +1,7 @@
 """How much of the bench frame's time is spent on tiles whose rays all fail the root gate?  Times the fused primary kernel on the
 whole 1920x1080 frame and on the bounding rectangle (tile-aligned, +1 super-tile margin) of the pixels that can enter the tree."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 pkg = e.load_package(); orc = e.load_oracle()
 sd = pkg.scenes.make_dragon(800_000)

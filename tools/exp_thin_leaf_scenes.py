@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 pkg = e.load_package()
 W, H = 1920, 1080
