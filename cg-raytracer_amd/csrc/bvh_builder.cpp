@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -373,11 +375,90 @@ struct TopBuilder {
         for (int i = 0; i < depth_left; i++) c *= 4u;
         return c;
     }
-    // SAH split of idx[b, e), full sweep on every axis; each side may hold at most `cap` items
+    // Large ranges: binned SAH (32 bins per axis over the centroid bounds, O(n) per split), then an in-place partition.  A
+    // plane is eligible only if both sides fit under the remaining depth; when none is, or the centroids coincide, the range
+    // is cut at an admissible position of its longest centroid axis (nth_element).
+    static const uint32_t BIN_THRESHOLD = 2048, NBINS = 32;
+    uint32_t split_binned(uint32_t b, uint32_t e, uint32_t kmin, uint32_t kmax) {
+        const uint32_t n = e - b;
+        float cmin[3], cmax[3];
+        for (int a = 0; a < 3; a++) {
+            cmin[a] = std::numeric_limits<float>::infinity();
+            cmax[a] = -cmin[a];
+        }
+        for (uint32_t i = b; i < e; i++)
+            for (int a = 0; a < 3; a++) {
+                const float c = cen[a][idx[i]];
+                cmin[a] = std::min(cmin[a], c);
+                cmax[a] = std::max(cmax[a], c);
+            }
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1;
+        uint32_t best_bin = 0;
+        for (int a = 0; a < 3; a++) {
+            const float ext = cmax[a] - cmin[a];
+            if (!(ext > 0.0f)) continue;
+            const float scale = (float)NBINS / ext;
+            Box6 bb[NBINS];
+            uint32_t bc[NBINS];
+            for (uint32_t k = 0; k < NBINS; k++) {
+                bb[k] = empty_box();
+                bc[k] = 0;
+            }
+            for (uint32_t i = b; i < e; i++) {
+                const uint32_t it = idx[i];
+                uint32_t k = (uint32_t)((cen[a][it] - cmin[a]) * scale);
+                if (k >= NBINS) k = NBINS - 1;
+                grow(bb[k], box[it]);
+                bc[k]++;
+            }
+            float ra[NBINS];
+            Box6 acc = empty_box();
+            for (uint32_t k = NBINS; k-- > 1;) {
+                grow(acc, bb[k]);
+                ra[k] = half_area(acc);
+            }
+            acc = empty_box();
+            uint32_t left = 0;
+            for (uint32_t k = 1; k < NBINS; k++) {  // plane between bin k-1 and bin k
+                grow(acc, bb[k - 1]);
+                left += bc[k - 1];
+                if (left < kmin || left > kmax) continue;
+                const float cost = half_area(acc) * (float)left + ra[k] * (float)(n - left);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_bin = k;
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            const float scale = (float)NBINS / (cmax[best_axis] - cmin[best_axis]);
+            const float c0 = cmin[best_axis];
+            const std::vector<float>& key = cen[best_axis];
+            auto mid = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t it) {
+                uint32_t k = (uint32_t)((key[it] - c0) * scale);
+                if (k >= NBINS) k = NBINS - 1;
+                return k < best_bin;
+            });
+            return (uint32_t)(mid - idx.begin());
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; a++)
+            if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+        const uint32_t k = std::min(std::max(n / 2, kmin), kmax);
+        const std::vector<float>& key = cen[axis];
+        std::nth_element(idx.begin() + b, idx.begin() + b + k, idx.begin() + e, [&](uint32_t p, uint32_t q) { return key[p] < key[q]; });
+        return b + k;
+    }
+
+    // SAH split of idx[b, e), full sweep on every axis (small ranges) or binned (large ones); each side may hold at most
+    // `cap` items
     uint32_t split(uint32_t b, uint32_t e, uint64_t cap) {
         const uint32_t n = e - b;
         const uint32_t kmin = (uint32_t)std::max<int64_t>(1, (int64_t)n - (int64_t)cap);
         const uint32_t kmax = (uint32_t)std::min<uint64_t>(n - 1, cap);
+        if (n > BIN_THRESHOLD) return split_binned(b, e, kmin, kmax);
         float best_cost = std::numeric_limits<float>::infinity();
         int best_axis = -1;
         uint32_t best_k = std::min(std::max(n / 2, kmin), kmax);
@@ -753,8 +834,14 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
             if (c > out.scene_absmax) out.scene_absmax = c;  // NaN coordinates never raise it
             if (!(c <= std::numeric_limits<float>::max())) out.geometry_finite = false;
         }
+    const auto t_a = std::chrono::steady_clock::now();
     if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
+    const auto t_b = std::chrono::steady_clock::now();
     if (opt.fast_tree != 0) build_fast_tree(out, opt.fast_tree > 0, opt.leaf_accel, opt.fast_open);
+    if (getenv("CGRT_BUILD_TIMES"))
+        fprintf(stderr, "build: reference tree + records %.3f s, leaf accelerators %.3f s, fast tree %.3f s\n",
+                std::chrono::duration<double>(t_a - t_start).count(), std::chrono::duration<double>(t_b - t_a).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
     // one 64-byte record array on the device: [packets | subnodes | tris]; make sub/tri references global
     if (out.packets.size() & 1u) {
         NodePacket pad;  // keeps every 128-byte accelerator node inside one 128-byte line (the array is 256-byte aligned)

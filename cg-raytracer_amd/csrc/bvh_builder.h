@@ -60,7 +60,7 @@ struct BuiltBvh {
 struct BuildOptions {
     bool leaf_accel = true;  // build the in-leaf accelerator (results are identical either way)
     int sub_leaf_tris = SUB_LEAF_TRIS;
-    int fast_open = 2;   // levels of the leaves' accelerators handed to the top tree's SAH as separate items (build_fast_tree)
+    int fast_open = SUB_MAX_DEPTH;  // levels of the leaves' accelerators handed to the top tree's SAH as separate items (build_fast_tree): all of them = a global tree over the runs
     int fast_tree = -1;  // certified walk's structures: -1 = whenever possible, except without in-leaf accelerators or below 16 triangles; 0 = never; 1 = whenever possible
 };
 
