@@ -923,12 +923,13 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     int nlev = 0;
     std::vector<unsigned long long> level_count;  // entries per evaluated level
     HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
+    if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data
     if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
         // level 0 = the primary rays that hit something, straight out of the fused primary kernel (pixels that miss are
         // black, main.cpp:293, and spawn nothing)
         uint32_t* const primary_hits = dctr.as<uint32_t>() + 4 * (size_t)max_level + 3;
         HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(),
-                                             ipix.as<int>(), primary_hits, nullptr, cw_primary));
+                                             ipix.as<int>(), primary_hits, nullptr, cw_primary, drgb.as<float>()));  // (also clears this rank's pixels)
         st.primary_rays = owned_pixels(F);
         uint32_t nhit0 = 0;
         HIP_TRY(hipMemcpy(&nhit0, primary_hits, sizeof(nhit0), hipMemcpyDeviceToHost));
@@ -979,15 +980,17 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             cnt = h[1];
         }
     }
-    if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data
-    if (nlev == 0) {  // nothing was hit (or max_level == 0): this rank's pixels are black
+    if (max_level < 1) {  // trace() returns black without tracing (main.cpp:267): no primary kernel ran, clear here
         HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
+    } else if (nlev == 0) {  // nothing was hit: the primary kernel has left this rank's pixels black
     } else {
-        for (int level = nlev - 2; level >= 0; level--)  // color = directColor + reflectedColor * ks (main.cpp:262), deepest level first
+        // color = directColor + reflectedColor * ks (main.cpp:262), deepest level first; the last fold (level 0 with level 1) is
+        // done by the kernel that scatters level 0 over the frame
+        for (int level = nlev - 2; level >= 1; level--)
             HIP_TRY(launch_fold(levels.as<float>() + (size_t)level * n * 8, levels.as<float>() + (size_t)(level + 1) * n * 8, level_count[level],
                                 nullptr));
-        HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
-        HIP_TRY(launch_write_rgb(levels.as<float>(), level_count[0], ipix.as<int>(), drgb.as<float>(), nullptr));
+        HIP_TRY(launch_write_rgb(levels.as<float>(), nlev >= 2 ? levels.as<float>() + (size_t)n * 8 : nullptr, level_count[0], ipix.as<int>(),
+                                 drgb.as<float>(), nullptr));
     }
     HIP_TRY(hipEventRecord(aux.e1, nullptr));
     HIP_TRY(hipEventSynchronize(aux.e1));

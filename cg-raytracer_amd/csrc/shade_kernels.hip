@@ -192,12 +192,22 @@ __global__ void k_fold(float4* __restrict__ lvl, const float4* __restrict__ chil
     lvl[2 * i] = make_float4(a.x + c.x * b.x, a.y + c.y * b.y, a.z + c.z * b.z, a.w);
 }
 
-__global__ void k_write_rgb(const float4* __restrict__ lvl0, unsigned long long n, const int* __restrict__ item_pixels, float* __restrict__ rgb) {
+// child_lvl (optional): the fold of level 0 with level 1 (k_fold's arithmetic) happens here, one launch less
+__global__ void k_write_rgb(const float4* __restrict__ lvl0, const float4* __restrict__ child_lvl, unsigned long long n,
+                            const int* __restrict__ item_pixels, float* __restrict__ rgb) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const long long pix = item_pixels[i];
     if (pix < 0) return;  // item outside the frame
-    const float4 a = lvl0[2 * i];
+    float4 a = lvl0[2 * i];
+    if (child_lvl) {
+        const float4 b = lvl0[2 * i + 1];
+        const int child = __float_as_int(b.w);
+        if ((__float_as_uint(a.w) & 1u) && !(b.z <= 0.01f) && child >= 0) {
+            const float4 c = child_lvl[2 * (unsigned long long)child];
+            a = make_float4(a.x + c.x * b.x, a.y + c.y * b.y, a.z + c.z * b.z, a.w);
+        }
+    }
     rgb[3 * pix] = a.x;
     rgb[3 * pix + 1] = a.y;
     rgb[3 * pix + 2] = a.z;
@@ -227,8 +237,10 @@ hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n,
                            reinterpret_cast<const float4*>(child_lvl), n);
     return hipGetLastError();
 }
-hipError_t launch_write_rgb(const float* lvl0, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_write_rgb, dim3(grid_for(n, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(lvl0), n, item_pixels, rgb);
+hipError_t launch_write_rgb(const float* lvl0, const float* child_lvl, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s) {
+    if (n)
+        hipLaunchKernelGGL(k_write_rgb, dim3(grid_for(n, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(lvl0),
+                           reinterpret_cast<const float4*>(child_lvl), n, item_pixels, rgb);
     return hipGetLastError();
 }
 

@@ -50,7 +50,8 @@ hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* 
 
 // primary frame for the shading wavefront: only the hits, appended to a compact list; count = one zeroed device word
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
-                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters = nullptr);
+                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters = nullptr,
+                                        float* rgb = nullptr);  // rgb (optional): the rank's pixels are cleared by the same kernel
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream);
 // shading wavefront (shade_kernels.hip); every level is a compact list of live paths
 // counters: 3 device words {shadow rays appended, mirror rays appended, hits}, zeroed by the caller
@@ -64,7 +65,8 @@ hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* 
                         const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s);
 // colour of level `lvl` entries += colour of their child (level lvl + 1) * ks  (main.cpp:262)
 hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s);
-hipError_t launch_write_rgb(const float* lvl0, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
+// child_lvl (optional): level 0 is folded with level 1 on the fly (colour + childColour * ks, main.cpp:262) instead of by launch_fold
+hipError_t launch_write_rgb(const float* lvl0, const float* child_lvl, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
 hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
                                hipStream_t s);
 hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,

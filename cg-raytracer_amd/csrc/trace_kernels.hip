@@ -41,11 +41,15 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
 template <bool COUNT, bool FAST>
 __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
                                                 float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count,
-                                                unsigned long long* counters) {
+                                                unsigned long long* counters, float* __restrict__ rgb) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
     const bool active = tile_pixel(F, lane, x, y);
+    if (active && rgb) {  // every pixel this rank owns starts black (main.cpp:293); the hits are written over it at the end of the frame
+        float* p = rgb + 3ull * ((unsigned long long)y * F.W + x);
+        p[0] = p[1] = p[2] = 0.0f;
+    }
     LaneCounters cnt;
     CgrtHitDev h;
     h.hit = 0;
@@ -287,14 +291,14 @@ hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
-                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters) {
+                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters, float* rgb) {
     if (F.nblocks == 0) return hipSuccess;
     const unsigned block = (unsigned)F.block;
     const bool fast = S.fast_root != REF_NONE;
     if (counters)
-        CGRT_LAUNCH2(k_trace_primary_compact, true, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters);
+        CGRT_LAUNCH2(k_trace_primary_compact, true, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
     else
-        CGRT_LAUNCH2(k_trace_primary_compact, false, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters);
+        CGRT_LAUNCH2(k_trace_primary_compact, false, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
     return hipGetLastError();
 }
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream) {
