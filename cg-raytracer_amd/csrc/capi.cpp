@@ -728,7 +728,9 @@ int cgrt_trace_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     if (rc) return rc;
     void *dh, *dn = nullptr;
     HIP_TRY(g.dev(1, npix * sizeof(CgrtHit), &dh));
-    HIP_TRY(lane_upload(g, 1, dh, hits, npix * sizeof(CgrtHit)));  // pixels outside the tiles keep caller data
+    // pixels outside the traced tiles keep caller data: seed the device frame with it -- unless this call writes every pixel
+    const bool whole_frame = (x0 == 0 && y0 == 0 && x1 == W && y1 == H && nranks == 1);
+    if (!whole_frame) HIP_TRY(lane_upload(g, 1, dh, hits, npix * sizeof(CgrtHit)));
     if (normals) {
         HIP_TRY(g.dev(2, npix * 12, &dn));
         HIP_TRY(lane_upload(g, 2, dn, normals, npix * 12));
