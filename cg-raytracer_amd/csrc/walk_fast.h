@@ -81,7 +81,7 @@ __device__ __forceinline__ void fast_test_run(const SceneDev& S, const uint32_t 
 }
 
 // The certificate's box part for record `rec` accepted at parameter t: every box on the reference's way to the record's
-// leaf is entered at t (see the header).  Reference arithmetic: ray_box_fast under RayFast::fd.
+// leaf is entered at t (see the header).  Reference arithmetic: ray_box_fast under RayFast::fd, ray_box + starts_in_box outside it.
 template <bool COUNT>
 __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W, const uint32_t rec, const float t, LaneCounters& cnt) {
     const uint32_t leaf = S.tri_leaf[rec - S.tri_base];
@@ -96,7 +96,17 @@ __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W,
         bool inside;
         // the geometric part of the box test with the reference's arithmetic (t = +inf: no `cur >= ray.t` rejection), then
         // cur <= t: see the header -- every ray.t the reference can hold before it accepts T is strictly above t
-        const bool geom = ray_box_fast<true>(f3(a.x, a.y, b.x), f3(b.y, c.x, c.y), W.o, W.d, R, __builtin_inff(), tb, inside);
+        // (a NaN parameter -- 0 / 0 on a zero direction component -- is never rejected by `cur >= ray.t`, nor skipped on pop by
+        // `ray.t < tSecond`: !(tb > t) says the same)
+        const F3 lo = f3(a.x, a.y, b.x), hi = f3(b.y, c.x, c.y);
+        bool geom;
+        if (R.fd) {
+            geom = ray_box_fast<true>(lo, hi, W.o, W.d, R, __builtin_inff(), tb, inside);
+        } else {  // outside the exact fast division's envelope: the reference's test as written (IEEE divisions, ternary ladders)
+            tb = 0.0f;
+            geom = ray_box(lo, hi, W.o, W.d, __builtin_inff(), tb);
+            inside = starts_in_box(W.o, lo, hi);
+        }
         ok = ok && (inside || (geom && !(tb > t)));
     }
     return ok;
@@ -298,7 +308,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
 }
 
 // The certified search for a whole wave.  `alive`: the lane carries a ray that passed the root gate, lies inside both
-// envelopes (W.P.regular, W.R.fd) and wants the certified walk; the other lanes only help in the quad tail.  Must be called
+// envelope (W.P.regular) and wants the certified walk; the other lanes only help in the quad tail.  Must be called
 // by all 64 lanes (wave-uniform control flow).  Returns, per alive lane, true when (W.t, W.hit_rec) now hold the answer the
 // MODE asks for (see WALK_*); false: W is untouched, take the exact walk.  qlen: WALK_OCCLUDED's |fromPosToLight|.
 template <bool COUNT, int MODE>
@@ -351,8 +361,8 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
 
 // BoundingVolumeHierarchy::intersect's mesh part (bvh.cpp:870-875) for the rays of a wave (one per `active` lane; call
 // with all 64 lanes; wave_stk / s_map: CGRT_WAVE_STACK / CGRT_WAVE_MAP of the kernel's dynamic LDS): root gate, then the
-// certified walk when the scene has a fast tree and the ray lies inside both envelopes (RayPre::regular, RayFast::fd), the
-// exact walk otherwise or when no certificate was obtained.
+// certified walk when the scene has a fast tree and the ray lies inside the search's envelope (RayPre::regular), the exact
+// walk otherwise or when no certificate was obtained.
 // MODE (see WALK_*): the exact walk answers WALK_ANYHIT by stopping after the first leaf that accepted a triangle -- the walk
 // up to there is the reference's, so the hit FLAG is the reference's (some acceptance happens upstream iff one happens in
 // the first leaf that has one); t and the record are those of that leaf, not the final ones -- and WALK_OCCLUDED with the
@@ -370,7 +380,7 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, 
     if (COUNT && entered) cnt.entered++;
     bool certified = false;
     if (FAST) {
-        const bool eligible = entered && W.P.regular && W.R.fd;
+        const bool eligible = entered && W.P.regular;
         if (__any(eligible)) certified = walk_fast_wave<COUNT, MODE>(S, eligible, W, qlen, wave_stk, s_map, cnt);
         if (COUNT && eligible && !certified) cnt.fallback++;
     }

@@ -239,3 +239,26 @@ def test_counted_render_reports_the_secondary_work(pkg):
     for k in ("tree_rays", "sub_visits", "tri_tests", "cert_boxes", "fallback_rays"):
         assert work["primary"][k] == cp[k]
     assert work["shadow"]["tree_rays"] > 0 and work["mirror"]["sub_visits"] > 0
+
+
+def test_axis_parallel_rays_are_certified_too(pkg, orc):
+    """Rays with zero direction components lie outside the exact fast division's envelope (RayFast::fd); their certificates
+    use the reference's box test as written (IEEE divisions, NaN-order-sensitive ternaries) and they still take the
+    certified walk: an orthographic grid straight down the z axis onto the dragon, bit-exact, with (almost) no exact steps."""
+    sd = pkg.scenes.make_dragon(60_000)
+    n = 200
+    xs, ys = np.meshgrid(np.linspace(-0.9, 0.9, n, dtype=np.float32), np.linspace(-0.9, 0.9, n, dtype=np.float32))
+    rays = np.zeros((n * n, 7), np.float32)
+    rays[:, 0], rays[:, 1], rays[:, 2] = xs.ravel(), ys.ravel(), -3.0
+    rays[:, 5] = 1.0  # direction (0, 0, 1): two zero components -> +-inf / NaN slab parameters upstream
+    rays[1::2, 5] = 0.5
+    rays[:, 6] = FMAX
+    sc, o = pkg.Scene(sd), orc.OracleScene(sd)
+    hits, normals = sc.intersect(_rays(pkg, rays))
+    _assert_hits_equal(hits, normals, o.intersect(rays), "orthographic grid")
+    c = sc.count_batch(_rays(pkg, rays))
+    assert c["tree_rays"] > 0.3 * n * n and (hits["hit"] == 1).sum() > 0.1 * n * n
+    assert c["fallback_rays"] < 0.02 * c["tree_rays"], c
+    sc.set_walk(False)
+    c0 = sc.count_batch(_rays(pkg, rays))
+    assert c["inner_visits"] < 0.05 * c0["inner_visits"]
