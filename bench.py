@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tris", type=int, default=800_000, help="triangles of the procedural dragon stand-in (87000 = the report's size)")
     ap.add_argument("--obj", type=str, default="", help="load this OBJ (centred + unit-scaled like scene.cpp:42) instead of the stand-in")
+    ap.add_argument("--standin", choices=["regular", "irregular"], default="regular",
+                    help="regular = the tessellated torus-knot tube (default); irregular = the same shape with scan-like density, slivers, noise and order")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
@@ -171,8 +173,8 @@ def main():
         scene_name = f"{os.path.basename(args.obj)} ({sd.ntris} tris, {sd.nmesh} mesh(es))"
         data = f"user-supplied OBJ {os.path.basename(args.obj)}"
     else:
-        sd = pkg.scenes.make_dragon(args.tris)
-        scene_name = f"dragon stand-in {sd.ntris} tris (1 mesh, 12-level reference BVH)"
+        sd = pkg.scenes.make_dragon(args.tris) if args.standin == "regular" else pkg.scenes.make_dragon_irregular(args.tris)
+        scene_name = f"dragon stand-in {sd.ntris} tris (1 mesh, 12-level reference BVH)" + ("" if args.standin == "regular" else ", irregular variant")
         data = "synthetic (procedural dragon stand-in: data/dragon.obj is absent from the reference checkout)"
     cam = pkg.scenes.default_camera(W, H)
     t0 = time.time()
@@ -366,7 +368,7 @@ def main():
             },
         }
     if rank == 0 and out is not None:
-        if world == 1 and args.workload == "primary" and not args.no_extras and scaling == "headline" and not args.obj and not (args.width and args.height):
+        if world == 1 and args.workload == "primary" and not args.no_extras and scaling == "headline" and not args.obj and args.standin == "regular" and not (args.width and args.height):
             # secondary lines of SURVEY.md section 8(d): the config-5 frame on this one GPU (base of the strong-scaling curve)
             # and the report's 87 K-triangle dragon beside the 800 K one
             extras = {}

@@ -346,6 +346,52 @@ def make_dragon(ntris_target: int = 800_000, seed: int = 20250117) -> SceneData:
     return sd
 
 
+def make_dragon_irregular(ntris_target: int = 800_000, seed: int = 20250117) -> SceneData:
+    """The dragon stand-in with what a scanned mesh has and a tessellated grid has not: irregular triangle density (a random
+    40 % of the base triangles are split into four, a random 30 % of those children again), a few percent of slivers (one
+    vertex pulled most of the way to the opposite edge's midpoint), vertex noise of a fraction of the local edge length, and
+    a random triangle order in the file.  ~ntris_target triangles, one mesh, deterministic.  Used by `bench.py --standin
+    irregular` to check that the numbers quoted on the regular stand-in carry over."""
+    rng = np.random.RandomState(seed + 1)
+    base = make_dragon(max(1000, int(ntris_target / 3.64)), seed)  # 0.6 + 0.4 * 4 * (0.7 + 0.3 * 4) = 3.64 triangles per base triangle
+    P = base.pos_nrm[:, 0:3].astype(np.float64).reshape(-1, 3, 3)
+    N = base.pos_nrm[:, 3:6].astype(np.float64).reshape(-1, 3, 3)
+
+    def split(P, N, mask):
+        keepP, keepN = P[~mask], N[~mask]
+        a, b, c = P[mask][:, 0], P[mask][:, 1], P[mask][:, 2]
+        na, nb, nc = N[mask][:, 0], N[mask][:, 1], N[mask][:, 2]
+        ab, bc, ca = (a + b) / 2, (b + c) / 2, (c + a) / 2
+        nab, nbc, nca = na + nb, nb + nc, nc + na
+        kids = [(a, ab, ca, na, nab, nca), (ab, b, bc, nab, nb, nbc), (ca, bc, c, nca, nbc, nc), (ab, bc, ca, nab, nbc, nca)]
+        cp = np.concatenate([np.stack(k[0:3], 1) for k in kids])
+        cn = np.concatenate([np.stack(k[3:6], 1) for k in kids])
+        cn /= np.maximum(np.linalg.norm(cn, axis=-1, keepdims=True), 1e-30)
+        return np.concatenate([keepP, cp]), np.concatenate([keepN, cn]), len(keepP)
+
+    P, N, nk = split(P, N, rng.uniform(size=len(P)) < 0.4)
+    m2 = np.zeros(len(P), bool)
+    m2[nk:] = rng.uniform(size=len(P) - nk) < 0.3
+    P, N, _ = split(P, N, m2)
+    edge = np.linalg.norm(P[:, 1] - P[:, 0], axis=-1)
+    P += rng.normal(size=P.shape) * (0.04 * edge)[:, None, None]  # (per corner: the mesh stays a triangle soup, like assimp's output)
+    sl = rng.uniform(size=len(P)) < 0.03
+    P[sl, 2] = P[sl, 2] + 0.97 * ((P[sl, 0] + P[sl, 1]) / 2 - P[sl, 2])
+    order = rng.permutation(len(P))
+    P, N = P[order], N[order]
+    ntri = len(P)
+    sd = SceneData(
+        pos_nrm=np.concatenate([P.reshape(-1, 3), N.reshape(-1, 3)], 1).astype(F32),
+        tri=np.arange(3 * ntri, dtype=np.uint32).reshape(ntri, 3),
+        tri_mesh=np.zeros(ntri, np.uint32),
+        materials=base.materials.copy(),
+        point_lights=base.point_lights.copy(),
+        name=f"dragon_irregular{ntri}",
+    )
+    center_and_scale_to_unit(sd)
+    return sd
+
+
 def make_blob(ntris_target: int = 2000, seed: int = 7) -> SceneData:
     """Small seeded procedural multi-mesh scene for fixtures: a bumpy sphere split into 3 meshes."""
     rng = np.random.RandomState(seed)

@@ -262,3 +262,17 @@ def test_axis_parallel_rays_are_certified_too(pkg, orc):
     sc.set_walk(False)
     c0 = sc.count_batch(_rays(pkg, rays))
     assert c["inner_visits"] < 0.05 * c0["inner_visits"]
+
+
+def test_irregular_standin_frame(pkg, orc):
+    """The scan-like variant of the stand-in (irregular density, slivers, noise, shuffled order): a 480x270 frame against the
+    oracle, certified walk by default, few fallbacks."""
+    sd = pkg.scenes.make_dragon_irregular(120_000)
+    W, H = 480, 270
+    cam = pkg.scenes.default_camera(W, H)
+    sc = pkg.Scene(sd)
+    assert sc.walk() == 1
+    hits, normals = sc.trace_primary(cam, W, H, want_normals=True)
+    _assert_hits_equal(hits, normals, orc.OracleScene(sd).intersect(sc.generate_rays(cam, W, H)), "irregular stand-in")
+    c = sc.count_primary(cam, W, H)
+    assert c["fallback_rays"] < 0.01 * c["tree_rays"] and (hits["hit"] == 1).mean() > 0.05
