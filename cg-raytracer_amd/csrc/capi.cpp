@@ -177,7 +177,7 @@ struct CgrtScene {
     struct WorkSlot {
         void* p = nullptr;
         size_t cap = 0;
-    } work[24];  // slots 0..20 are in use (render_impl)
+    } work[32];  // slots 0..28 are in use (render_impl)
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
@@ -862,9 +862,13 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     // one per entry, so the number of primary hits bounds every list, and n bounds that); the shadow list of a level
     // holds at most entries * L rays.  hits/normals/rays/pixels alternate between two sets (a level's mirror batch is
     // traversed on a second stream while the level itself is still being shaded).
-    WsBuf rays[2] = {{s, 0}, {s, 1}}, hits[2] = {{s, 2}, {s, 3}}, normals[2] = {{s, 4}, {s, 5}}, pix[2] = {{s, 6}, {s, 7}}, ipix{s, 8},
-          srays{s, 9}, shits{s, 10}, sdist{s, 11}, sslot{s, 12}, dlights{s, 13}, levels{s, 14}, drgb{s, 15}, dctr{s, 16}, dslights{s, 17},
-          dunits{s, 18}, dlit{s, 19}, dwork{s, 20};
+    // hits/normals/rays/pixels rotate through three sets (level l reads set l % 3 and writes its mirror rays into set (l + 1) % 3;
+    // level 1 is evaluated on a second stream while level 0 is still being shaded, so its mirror rays need a third set), the
+    // shadow lists through two.
+    WsBuf rays[3] = {{s, 0}, {s, 1}, {s, 21}}, hits[3] = {{s, 2}, {s, 3}, {s, 22}}, normals[3] = {{s, 4}, {s, 5}, {s, 23}},
+          pix[3] = {{s, 6}, {s, 7}, {s, 24}}, ipix{s, 8}, srays[2] = {{s, 9}, {s, 25}}, shits[2] = {{s, 10}, {s, 26}}, sdist[2] = {{s, 11}, {s, 27}},
+          sslot[2] = {{s, 12}, {s, 28}}, dlights{s, 13}, levels{s, 14}, drgb{s, 15}, dctr{s, 16}, dslights{s, 17}, dunits{s, 18}, dlit{s, 19},
+          dwork{s, 20};
     unsigned long long *cw_primary = nullptr, *cw_shadow = nullptr, *cw_mirror = nullptr;
     if (counted) {
         HIP_TRY(dwork.alloc(3 * 8 * sizeof(unsigned long long)));
@@ -874,16 +878,18 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         cw_mirror = cw_primary + 16;
     }
     HIP_TRY(ipix.alloc(n * 4));  // pixels of level 0, kept to the end
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         HIP_TRY(rays[k].alloc(n * 28));
         HIP_TRY(hits[k].alloc(n * sizeof(CgrtHit)));
         HIP_TRY(normals[k].alloc(n * 12));
         HIP_TRY(pix[k].alloc(n * 4));
     }
-    HIP_TRY(srays.alloc(n * L * 28));
-    HIP_TRY(shits.alloc(n * L * sizeof(CgrtHit)));
-    HIP_TRY(sdist.alloc(n * L * 4));
-    HIP_TRY(sslot.alloc(n * L * 4));
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(srays[k].alloc(n * L * 28));
+        HIP_TRY(shits[k].alloc(n * L * sizeof(CgrtHit)));
+        HIP_TRY(sdist[k].alloc(n * L * 4));
+        HIP_TRY(sslot[k].alloc(n * L * 4));
+    }
     HIP_TRY(dlights.alloc((size_t)L * 24));
     HIP_TRY(levels.alloc((size_t)(max_level > 0 ? max_level : 1) * n * 32));
     HIP_TRY(drgb.alloc(npix * 12));
@@ -936,39 +942,63 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         uint32_t nhit0 = 0;
         HIP_TRY(hipMemcpy(&nhit0, primary_hits, sizeof(nhit0), hipMemcpyDeviceToHost));
         unsigned long long cnt = nhit0;
-        for (int level = 0; level < max_level && cnt > 0; level++) {
-            const int a = level & 1, b = a ^ 1;  // this level's buffer set, the next level's
+        const float* const mats = static_cast<const float*>(s->d_materials);
+        int level = 0;
+        while (level < max_level && cnt > 0) {
+            const int a = level % 3, b = (level + 1) % 3, q = level & 1;  // this level's buffer set, the next level's, this level's shadow set
             const int spawn = level + 1 < max_level;
             const int* cur_pix = level == 0 ? ipix.as<int>() : pix[a].as<int>();
             uint32_t* ctr = dctr.as<uint32_t>() + 4 * (size_t)level;
             float* lvl = levels.as<float>() + (size_t)level * n * 8;
-            HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), cur_pix, cnt,
-                                 static_cast<const float*>(s->d_materials), dlights.as<float>(), L, spawn, srays.as<float>(), sdist.as<float>(),
-                                 sslot.as<int>(), lvl, rays[b].as<float>(), pix[b].as<int>(), ctr, nullptr));
+            HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), cur_pix, cnt, mats, dlights.as<float>(), L,
+                                 spawn, srays[q].as<float>(), sdist[q].as<float>(), sslot[q].as<int>(), lvl, rays[b].as<float>(), pix[b].as<int>(),
+                                 ctr, nullptr));
             // Level 0's mirror batch runs on the second stream, beside level 0's shadow batch (two batches of a few hundred
             // thousand rays each; its grid covers the list's capacity -- one mirror ray per entry -- and the kernel stops at the
-            // appended count).  Deeper levels are small and often empty: their mirror batch is launched after the level's
-            // sync, exactly sized, or not at all.
+            // appended count).  Without spherical lights the whole of level 1 follows it there -- spawn, shadow list, shading,
+            // level 2's mirror batch: none of it needs level 0's shading, all of it is sized by counts on the device -- so that
+            // level 1's tail overlaps level 0's.  Deeper levels are small and often empty: they run one after the other,
+            // exactly sized after each level's read-back, or not at all.
             const bool overlap = spawn && level == 0;
+            const bool pipelined = overlap && SL == 0;
+            const int spawn1 = 2 < max_level;
+            uint32_t* const ctr1 = dctr.as<uint32_t>() + 4;
             if (overlap) {
                 HIP_TRY(hipEventRecord(aux.spawned, nullptr));
                 HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
                 HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cnt, hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, aux.s,
                                            ctr + 1));
+                if (pipelined) {
+                    const int a1 = b, b1 = 2, q1 = 1;
+                    float* lvl1 = levels.as<float>() + (size_t)n * 8;
+                    HIP_TRY(launch_spawn(rays[a1].as<float>(), hits[a1].as<CgrtHitDev>(), normals[a1].as<float>(), pix[a1].as<int>(), cnt, mats,
+                                         dlights.as<float>(), L, spawn1, srays[q1].as<float>(), sdist[q1].as<float>(), sslot[q1].as<int>(), lvl1,
+                                         rays[b1].as<float>(), pix[b1].as<int>(), ctr1, aux.s, ctr + 1));
+                    if (L)
+                        HIP_TRY(launch_trace_shadow(s->dev, srays[q1].as<float>(), sdist[q1].as<float>(), cnt * L, shits[q1].as<CgrtHitDev>(), aux.s,
+                                                    ctr1 + 0, cw_shadow));
+                    HIP_TRY(launch_shade(rays[a1].as<float>(), hits[a1].as<CgrtHitDev>(), normals[a1].as<float>(), shits[q1].as<CgrtHitDev>(),
+                                         sdist[q1].as<float>(), sslot[q1].as<int>(), cnt, mats, dlights.as<float>(), L, dslights.as<float>(), SL,
+                                         dlit.as<uint32_t>(), Q.samples, lvl1, aux.s, ctr + 1));
+                    if (spawn1)
+                        HIP_TRY(launch_trace_batch(s->dev, rays[b1].as<float>(), cnt, hits[b1].as<CgrtHitDev>(), normals[b1].as<float>(), cw_mirror,
+                                                   aux.s, ctr1 + 1));
+                }
                 HIP_TRY(hipEventRecord(aux.traced, aux.s));
             }
             if (L)
-                HIP_TRY(launch_trace_shadow(s->dev, srays.as<float>(), sdist.as<float>(), cnt * L, shits.as<CgrtHitDev>(), nullptr, ctr + 0, cw_shadow));
+                HIP_TRY(launch_trace_shadow(s->dev, srays[q].as<float>(), sdist[q].as<float>(), cnt * L, shits[q].as<CgrtHitDev>(), nullptr, ctr + 0,
+                                            cw_shadow));
             if (SL) {
                 Q.level = (uint32_t)level;
                 HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));
                 HIP_TRY(launch_soft_shadow(s->dev, Q, rays[a].as<float>(), hits[a].as<CgrtHitDev>(), cur_pix, cnt, dlit.as<uint32_t>(),
                                            soft->closest_hit == 0, nullptr));
             }
-            HIP_TRY(launch_shade(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), shits.as<CgrtHitDev>(), sdist.as<float>(),
-                                 sslot.as<int>(), cnt, static_cast<const float*>(s->d_materials), dlights.as<float>(), L, dslights.as<float>(),
-                                 SL, dlit.as<uint32_t>(), Q.samples, lvl, nullptr));
-            if (overlap) HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));  // the next level (and the end of the frame) need the mirror hits
+            HIP_TRY(launch_shade(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), shits[q].as<CgrtHitDev>(), sdist[q].as<float>(),
+                                 sslot[q].as<int>(), cnt, mats, dlights.as<float>(), L, dslights.as<float>(), SL, dlit.as<uint32_t>(), Q.samples, lvl,
+                                 nullptr));
+            if (overlap) HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));  // the next level (and the end of the frame) need the second stream's results
             nlev = level + 1;
             level_count.push_back(cnt);
             uint32_t h[4];
@@ -977,9 +1007,22 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             st.reflection_rays += h[1];
             st.soft_shadow_rays += (uint64_t)h[2] * SL * Q.samples;
             if (!spawn || h[1] == 0) break;
+            if (pipelined) {  // level 1 has been evaluated on the second stream, and level 2's rays traversed
+                uint32_t h1[4];
+                HIP_TRY(hipMemcpy(h1, ctr1, sizeof(h1), hipMemcpyDeviceToHost));
+                nlev = 2;
+                level_count.push_back(h[1]);
+                st.shadow_rays += h1[0];
+                st.reflection_rays += h1[1];
+                if (!spawn1 || h1[1] == 0) break;
+                cnt = h1[1];
+                level = 2;
+                continue;
+            }
             if (!overlap)
                 HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), h[1], hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, nullptr));
             cnt = h[1];
+            level += 1;
         }
     }
     if (max_level < 1) {  // trace() returns black without tracing (main.cpp:267): no primary kernel ran, clear here

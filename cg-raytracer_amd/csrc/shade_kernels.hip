@@ -55,8 +55,13 @@ __global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_spawn(const float* __restr
                                                             const float* __restrict__ lights, unsigned nlights, int spawn,
                                                             float* __restrict__ srays, float* __restrict__ sdist, int* __restrict__ sslot,
                                                             float4* __restrict__ lvl, float* __restrict__ next_rays,
-                                                            int* __restrict__ next_pixels, uint32_t* __restrict__ counters) {
+                                                            int* __restrict__ next_pixels, uint32_t* __restrict__ counters,
+                                                            const uint32_t* __restrict__ dcount) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dcount) {  // the list's length is only known on the device (the grid covers its capacity n)
+        const unsigned long long present = *dcount;
+        n = present < n ? present : n;
+    }
     const bool in = i < n;
     const bool hit = in && hits[i].hit != 0;
     F3 pointOn = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 0.f), ks = f3(0.f, 0.f, 0.f);
@@ -124,8 +129,13 @@ __global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_shade(const float* __restr
                                                             unsigned long long n, const float* __restrict__ materials,
                                                             const float* __restrict__ lights, unsigned nlights,
                                                             const float* __restrict__ slights, unsigned nslights,
-                                                            const uint32_t* __restrict__ lit, unsigned samples, float4* __restrict__ lvl) {
+                                                            const uint32_t* __restrict__ lit, unsigned samples, float4* __restrict__ lvl,
+                                                            const uint32_t* __restrict__ dcount) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dcount) {
+        const unsigned long long present = *dcount;
+        n = present < n ? present : n;
+    }
     if (i >= n) return;
     float4 out0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (hits[i].hit) {
@@ -217,18 +227,19 @@ static inline unsigned grid_for(unsigned long long n, unsigned block) { return (
 
 hipError_t launch_spawn(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, unsigned long long n,
                         const float* materials, const float* lights, unsigned nlights, int spawn, float* srays, float* sdist, int* sslot,
-                        float* lvl, float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s) {
+                        float* lvl, float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s, const uint32_t* dcount) {
     if (n)
         hipLaunchKernelGGL(k_spawn, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, normals, pixels, n, materials,
-                           lights, nlights, spawn, srays, sdist, sslot, reinterpret_cast<float4*>(lvl), next_rays, next_pixels, counters);
+                           lights, nlights, spawn, srays, sdist, sslot, reinterpret_cast<float4*>(lvl), next_rays, next_pixels, counters, dcount);
     return hipGetLastError();
 }
 hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
                         const int* sslot, unsigned long long n, const float* materials, const float* lights, unsigned nlights,
-                        const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s) {
+                        const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s,
+                        const uint32_t* dcount) {
     if (n)
         hipLaunchKernelGGL(k_shade, dim3(grid_for(n, CGRT_SHADE_BLOCK)), dim3(CGRT_SHADE_BLOCK), 0, s, rays, hits, normals, shits, sdist, sslot, n,
-                           materials, lights, nlights, slights, nslights, lit, samples, reinterpret_cast<float4*>(lvl));
+                           materials, lights, nlights, slights, nslights, lit, samples, reinterpret_cast<float4*>(lvl), dcount);
     return hipGetLastError();
 }
 hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s) {

@@ -58,11 +58,12 @@ hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream)
 // k_spawn: shadow rays of every hit -> the level's shadow list; mirror rays -> the next level's list; lvl[2i+1] = {ks, child}
 hipError_t launch_spawn(const float* rays, const CgrtHitDev* hits, const float* normals, const int* pixels, unsigned long long n,
                         const float* materials, const float* lights, unsigned nlights, int spawn, float* srays, float* sdist, int* sslot,
-                        float* lvl, float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s);
+                        float* lvl, float* next_rays, int* next_pixels, uint32_t* counters, hipStream_t s, const uint32_t* dcount = nullptr);
 // k_shade: lvl[2i] = {direct light, flags}
 hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* normals, const CgrtHitDev* shits, const float* sdist,
                         const int* sslot, unsigned long long n, const float* materials, const float* lights, unsigned nlights,
-                        const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s);
+                        const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s,
+                        const uint32_t* dcount = nullptr);  // dcount (optional): device word with the list's length (<= n, the capacity the grid covers)
 // colour of level `lvl` entries += colour of their child (level lvl + 1) * ks  (main.cpp:262)
 hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s);
 // child_lvl (optional): level 0 is folded with level 1 on the fly (colour + childColour * ks, main.cpp:262) instead of by launch_fold
