@@ -929,6 +929,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     HIP_TRY(hipEventCreate(&aux.e1));
     HIP_TRY(hipEventRecord(aux.e0, nullptr));
     int nlev = 0;
+    bool finished = false;  // the frame's last kernels and its closing event have been issued inside the level loop
     std::vector<unsigned long long> level_count;  // entries per evaluated level
     HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
     if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data
@@ -1001,15 +1002,32 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             if (overlap) HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));  // the next level (and the end of the frame) need the second stream's results
             nlev = level + 1;
             level_count.push_back(cnt);
-            uint32_t h[4];
-            HIP_TRY(hipMemcpy(h, ctr, sizeof(h), hipMemcpyDeviceToHost));  // also the level's sync point
+            if (pipelined && !spawn1) {
+                // Depth 2 (the reference's own depth, main.cpp:267): both levels are in flight or done and nothing further depends
+                // on their counts -- the frame is finished without a host round trip (an entry of level 0 without a mirror ray
+                // carries child = -1, so the scatter kernel can fold with level 1 whether or not level 1 has entries); the
+                // counts are read after the frame's closing event.
+                HIP_TRY(launch_write_rgb(levels.as<float>(), levels.as<float>() + (size_t)n * 8, cnt, ipix.as<int>(), drgb.as<float>(), nullptr));
+                finished = true;
+                HIP_TRY(hipEventRecord(aux.e1, nullptr));
+                uint32_t h2[8];
+                HIP_TRY(hipMemcpy(h2, ctr, sizeof(h2), hipMemcpyDeviceToHost));  // levels 0 and 1, adjacent
+                st.shadow_rays += (uint64_t)h2[0] + h2[4];
+                st.reflection_rays += (uint64_t)h2[1] + h2[5];
+                if (h2[1] > 0) {
+                    nlev = 2;
+                    level_count.push_back(h2[1]);
+                }
+                break;
+            }
+            uint32_t h[8];
+            HIP_TRY(hipMemcpy(h, ctr, pipelined ? sizeof(h) : sizeof(h) / 2, hipMemcpyDeviceToHost));  // also the level's sync point (pipelined: levels 0 and 1, adjacent)
             st.shadow_rays += h[0];
             st.reflection_rays += h[1];
             st.soft_shadow_rays += (uint64_t)h[2] * SL * Q.samples;
             if (!spawn || h[1] == 0) break;
             if (pipelined) {  // level 1 has been evaluated on the second stream, and level 2's rays traversed
-                uint32_t h1[4];
-                HIP_TRY(hipMemcpy(h1, ctr1, sizeof(h1), hipMemcpyDeviceToHost));
+                const uint32_t* h1 = h + 4;
                 nlev = 2;
                 level_count.push_back(h[1]);
                 st.shadow_rays += h1[0];
@@ -1025,7 +1043,8 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             level += 1;
         }
     }
-    if (max_level < 1) {  // trace() returns black without tracing (main.cpp:267): no primary kernel ran, clear here
+    if (finished) {
+    } else if (max_level < 1) {  // trace() returns black without tracing (main.cpp:267): no primary kernel ran, clear here
         HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
     } else if (nlev == 0) {  // nothing was hit: the primary kernel has left this rank's pixels black
     } else {
@@ -1037,7 +1056,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         HIP_TRY(launch_write_rgb(levels.as<float>(), nlev >= 2 ? levels.as<float>() + (size_t)n * 8 : nullptr, level_count[0], ipix.as<int>(),
                                  drgb.as<float>(), nullptr));
     }
-    HIP_TRY(hipEventRecord(aux.e1, nullptr));
+    if (!finished) HIP_TRY(hipEventRecord(aux.e1, nullptr));
     HIP_TRY(hipEventSynchronize(aux.e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, aux.e0, aux.e1));

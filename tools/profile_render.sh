@@ -12,6 +12,8 @@ rows = list(csv.DictReader(open("$out/trace/t_kernel_trace.csv")))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last frame of the last scene: the last 9 kernels (generate, items, trace, [spawn, trace, shade] x levels..., combine)
 tail = rows[-14:]
+t0 = int(tail[0]["Start_Timestamp"])
 for r in tail:
-    print("%-40s %8.1f us  grid %s" % (r["Kernel_Name"][:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", r.get("Grid_Size_X", "?"))))
+    print("%-40s start %7.1f  end %7.1f  (%6.1f us)  grid %s" % (r["Kernel_Name"][:40], (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
+                                                           (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", r.get("Grid_Size_X", "?"))))
 PY
