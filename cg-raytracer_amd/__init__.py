@@ -106,7 +106,7 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/cgrt.h declares
 EXPORTS = [
-    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
+    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_scene_build_info", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
     "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
     L.cgrt_set_fast_tree.argtypes = [i32]
     L.cgrt_scene_set_walk.argtypes = [vp, i32]
     L.cgrt_scene_walk.argtypes = [vp]
+    L.cgrt_scene_build_info.argtypes = [vp, vp]
     L.cgrt_get_nodes.argtypes = [vp, vp, vp]
     L.cgrt_leaf_prims.argtypes = [vp, i32, vp, u32]
     L.cgrt_leaf_prims.restype = C.c_int64
@@ -277,6 +278,12 @@ class Scene:
     def walk(self) -> int:
         """1 = certified walk (fast tree + certificate, exact walk as fallback), 0 = exact walk only."""
         return int(lib().cgrt_scene_walk(self._h))
+
+    def build_info(self) -> dict:
+        """What the host builder decided: fast tree built?, leaves with a degenerate float plane, finite geometry?, leaf count."""
+        out = np.zeros(4, np.uint32)
+        _check(lib().cgrt_scene_build_info(self._h, _ptr(out)))
+        return dict(fast_tree=bool(out[0]), wild_leaves=int(out[1]), geometry_finite=bool(out[2]), leaves=int(out[3]))
 
     # ---- introspection ----
     def num_levels(self) -> int:

@@ -384,6 +384,16 @@ int cgrt_scene_set_walk(CgrtScene* s, int certified) {
     s->dev.fast_root = certified ? s->fast_root : REF_NONE;
     return CGRT_OK;
 }
+int cgrt_scene_build_info(const CgrtScene* s, uint32_t* out4) {
+    if (!s || !out4) return fail(CGRT_E_ARG, "NULL argument");
+    uint32_t wild = 0;
+    for (uint8_t w : s->bvh.leaf_wild) wild += w;
+    out4[0] = s->bvh.fast_root != REF_NONE ? 1u : 0u;
+    out4[1] = wild;
+    out4[2] = s->bvh.geometry_finite ? 1u : 0u;
+    out4[3] = (uint32_t)s->bvh.leaves.size();
+    return CGRT_OK;
+}
 int cgrt_scene_walk(const CgrtScene* s) { return s ? (s->dev.fast_root != REF_NONE ? 1 : 0) : fail(CGRT_E_ARG, "scene is NULL"); }
 int cgrt_num_subnodes(const CgrtScene* s) { return s ? (int)s->bvh.subnodes.size() : fail(CGRT_E_ARG, "scene is NULL"); }
 

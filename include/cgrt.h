@@ -125,6 +125,10 @@ int cgrt_set_primary_mode(int mode);
 int cgrt_set_fast_tree(int mode);
 int cgrt_scene_set_walk(CgrtScene* scene, int certified);
 int cgrt_scene_walk(const CgrtScene* scene);
+/* What the host builder decided (also for host-only scenes): out4 = {1 if the fast tree was built, number of reference leaves
+ * that hold a triangle whose float plane degenerates (such leaves keep the linear scan and veto the fast tree), 1 if every vertex
+ * coordinate is finite, number of reference leaves}. */
+int cgrt_scene_build_info(const CgrtScene* scene, uint32_t* out4);
 
 /* BoundingVolumeHierarchy::numLevels() (bvh.cpp:214-224). */
 int cgrt_num_levels(const CgrtScene* scene);

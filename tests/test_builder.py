@@ -78,3 +78,49 @@ def test_record_layout_is_consistent(pkg, scene_data, name, accel, run):
             assert (s.num_subnodes() > 0) == accel
     finally:
         pkg.set_leaf_accel(True, 0)
+
+
+def test_fast_tree_policy_and_layout(pkg, scene_data):
+    """Host-only builds: when the certified walk's structures exist, and that they are consistent (cgrt_debug_check_layout walks
+    the fast tree down to its runs: every triangle record reachable exactly once, depth within the stack bound, paths ending
+    in their leaf's box, tri_leaf matching the leaf table)."""
+    d = pkg.Scene(pkg.scenes.make_dragon(20_000), device=-1)
+    assert d.build_info()["fast_tree"] and d.build_info()["wild_leaves"] == 0
+    d.check_layout()
+    for name, want in (("monkey", True), ("cornell", True), ("dodge", True), ("cube", False), ("triangle", False)):  # fewer than 16 triangles: exact walk
+        s = pkg.Scene(scene_data(name), device=-1)
+        assert s.build_info()["fast_tree"] == want, name
+        s.check_layout()
+    try:
+        pkg.set_fast_tree(1)
+        s = pkg.Scene(scene_data("cube"), device=-1)
+        assert s.build_info()["fast_tree"]
+        s.check_layout()
+        pkg.set_fast_tree(0)
+        assert not pkg.Scene(pkg.scenes.make_dragon(20_000), device=-1).build_info()["fast_tree"]
+    finally:
+        pkg.set_fast_tree(-1)
+    try:
+        pkg.set_leaf_accel(False)
+        assert not pkg.Scene(pkg.scenes.make_dragon(20_000), device=-1).build_info()["fast_tree"]  # linear leaves were asked for
+    finally:
+        pkg.set_leaf_accel(True)
+
+
+def test_degenerate_float_planes_veto_the_fast_tree(pkg):
+    """Scaled by 2^38 the larger triangles of a scene overflow |cross|^2: normalize gives n = (0, 0, 0), D = 0, and the reference
+    accepts such a triangle for EVERY ray (dot(o, n) == D).  The builder must notice: those leaves keep the linear scan, the
+    scene gets no fast tree; a NaN vertex (inert plane) or an infinite one (geometry not finite) are told apart."""
+    sd = pkg.scenes.make_blob(4000, seed=3)
+    big = sd.pos_nrm.copy()
+    big[:, 0:3] *= np.float32(2.0 ** 40)
+    s = pkg.Scene(pkg.scenes.SceneData(pos_nrm=big, tri=sd.tri, tri_mesh=sd.tri_mesh, materials=sd.materials), device=-1)
+    info = s.build_info()
+    assert info["wild_leaves"] > 0 and not info["fast_tree"] and info["geometry_finite"]
+    s.check_layout()
+    ok = pkg.Scene(sd, device=-1).build_info()
+    assert ok["wild_leaves"] == 0 and ok["fast_tree"]
+    inf = sd.pos_nrm.copy()
+    inf[7, 1] = np.inf
+    i2 = pkg.Scene(pkg.scenes.SceneData(pos_nrm=inf, tri=sd.tri, tri_mesh=sd.tri_mesh, materials=sd.materials), device=-1).build_info()
+    assert not i2["geometry_finite"] and not i2["fast_tree"]
