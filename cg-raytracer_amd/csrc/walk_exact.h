@@ -178,6 +178,70 @@ __device__ __forceinline__ TriEval eval_record(const float4 a, const float4 b, c
     E.inside = point_in_triangle(v0, v1, v2, n, p);
     return E;
 }
+// Two records at once on the packed FP32 pipe (v_pk_mul_f32 / v_pk_add_f32: two IEEE single operations per issue, each
+// component rounded exactly like the scalar instruction).  The expression trees are eval_record's, component for
+// component -- products and sums stay separate instructions (-ffp-contract=off covers vector types), the operand order is
+// glm's -- so E0/E1 carry the same bits as two eval_record calls; the division has no packed form and stays scalar.
+#ifndef CGRT_PACKED_PAIR
+#define CGRT_PACKED_PAIR 1
+#endif
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct P3 {
+    f2v x, y, z;
+};
+__device__ __forceinline__ f2v splat2(const float s) { return (f2v){s, s}; }
+__device__ __forceinline__ P3 p3(const f2v x, const f2v y, const f2v z) {
+    P3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+__device__ __forceinline__ P3 p3_pair(const F3 a, const F3 b) { return p3((f2v){a.x, b.x}, (f2v){a.y, b.y}, (f2v){a.z, b.z}); }
+__device__ __forceinline__ P3 p3_splat(const F3 a) { return p3(splat2(a.x), splat2(a.y), splat2(a.z)); }
+__device__ __forceinline__ P3 sub(const P3 a, const P3 b) { return p3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ P3 add(const P3 a, const P3 b) { return p3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ P3 scale(const P3 a, const f2v s) { return p3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f2v dot(const P3 a, const P3 b) {
+    const f2v px = a.x * b.x, py = a.y * b.y, pz = a.z * b.z;
+    return (px + py) + pz;
+}
+__device__ __forceinline__ P3 cross(const P3 a, const P3 b) {
+    return p3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ void eval_pair(const float4 a0, const float4 b0, const float4 c0, const float4 e0, const float4 a1, const float4 b1,
+                                          const float4 c1, const float4 e1, const F3 o, const F3 d, TriEval& E0, TriEval& E1) {
+#if CGRT_PACKED_PAIR
+    const P3 v0 = p3_pair(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
+    const P3 v1 = p3_pair(f3(a0.w, b0.x, b0.y), f3(a1.w, b1.x, b1.y));
+    const P3 v2 = p3_pair(f3(b0.z, b0.w, c0.x), f3(b1.z, b1.w, c1.x));
+    const P3 n = p3_pair(f3(c0.y, c0.z, c0.w), f3(c1.y, c1.z, c1.w));
+    const P3 po = p3_splat(o), pd = p3_splat(d);
+    const float D0 = e0.x, D1 = e1.x;
+    E0.k = (int)__float_as_uint(e0.w);
+    E1.k = (int)__float_as_uint(e1.w);
+    const f2v on = dot(po, n);
+    const f2v den = dot(pd, n);
+    E0.onp = (on.x == D0);
+    E1.onp = (on.y == D1);
+    E0.den_ok = !(den.x == 0);
+    E1.den_ok = !(den.y == 0);
+    const f2v num = (f2v){D0, D1} - on;
+    const float q0 = num.x / den.x, q1 = num.y / den.y;
+    E0.tt = E0.onp ? 0.0f : q0;
+    E1.tt = E1.onp ? 0.0f : q1;
+    const P3 p = add(po, scale(pd, (f2v){E0.tt, E1.tt}));
+    // pointInTriangle (ray_tracing.cpp:23-38), both records
+    const P3 e01 = sub(v1, v0), e12 = sub(v2, v1), e20 = sub(v0, v2);
+    const P3 q0v = sub(p, v0), q1v = sub(p, v1), q2v = sub(p, v2);
+    const f2v s0 = dot(n, cross(e01, q0v)), s1 = dot(n, cross(e12, q1v)), s2 = dot(n, cross(e20, q2v));
+    E0.inside = s0.x >= 0 && s1.x >= 0 && s2.x >= 0;
+    E1.inside = s0.y >= 0 && s1.y >= 0 && s2.y >= 0;
+#else
+    E0 = eval_record(a0, b0, c0, e0, o, d);
+    E1 = eval_record(a1, b1, c1, e1, o, d);
+#endif
+}
 __device__ __forceinline__ void apply_eval(const TriEval& E, const uint32_t rec, LeafScan& L) {
     const bool onp_take = E.onp && E.inside && (E.k > L.onp_k);
     L.onp_k = onp_take ? E.k : L.onp_k;
@@ -199,8 +263,8 @@ __device__ __forceinline__ void test_pair(const SceneDev& S, const uint32_t firs
     const uint32_t j = (n > 1) ? 4u : 0u;  // a run of one: the second slot re-reads the first record and is not applied
     const float4 a0 = q[0], b0 = q[1], c0 = q[2], e0 = q[3];
     const float4 a1 = q[j], b1 = q[j + 1], c1 = q[j + 2], e1 = q[j + 3];
-    const TriEval E0 = eval_record(a0, b0, c0, e0, o, d);
-    const TriEval E1 = eval_record(a1, b1, c1, e1, o, d);
+    TriEval E0, E1;
+    eval_pair(a0, b0, c0, e0, a1, b1, c1, e1, o, d, E0, E1);
     apply_eval(E0, first, L);
     if (n > 1) apply_eval(E1, first + 1, L);
 }
@@ -248,6 +312,33 @@ __device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P
         const uint2 m0 = *reinterpret_cast<const uint2*>(q + 3);
         const float4 a1 = q[4], b1 = q[5], c1 = q[6];
         const uint2 m1 = *reinterpret_cast<const uint2*>(q + 7);
+#ifdef CGRT_EXP_EXTRA_LOADS  // experiment only: re-read quarters of the same record (L1 hits) to load the memory pipe
+        {
+            int z;  // an opaque zero: plain (L1-cached) loads the compiler cannot merge with the real ones
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            const float4* vq = q + z;
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < CGRT_EXP_EXTRA_LOADS; i++) {
+                const float4 x = vq[i < 3 ? i : i + 1];
+                acc += x.x;
+            }
+            if (acc == 1.2345e-30f) sp = 0;
+        }
+#endif
+#ifdef CGRT_EXP_EXTRA_VALU  // experiment only: CGRT_EXP_EXTRA_VALU additional fma per node step
+        {
+            float x0 = P.inv.x, x1 = P.inv.y, x2 = P.inv.z, x3 = P.oin.x;
+#pragma unroll
+            for (int i = 0; i < CGRT_EXP_EXTRA_VALU / 4; i++) {
+                x0 = __builtin_fmaf(x0, a0.x, x1);
+                x1 = __builtin_fmaf(x1, a0.y, x2);
+                x2 = __builtin_fmaf(x2, a0.z, x3);
+                x3 = __builtin_fmaf(x3, a0.w, x0);
+            }
+            if ((x0 + x1) + (x2 + x3) == 1.2345e-30f) sp = 0;
+        }
+#endif
         float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
         slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
         slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);

@@ -71,8 +71,8 @@ __device__ __forceinline__ void fast_test_run(const SceneDev& S, const uint32_t 
         const uint32_t j = (n > 1) ? 4u : 0u;
         const float4 a0 = q[0], b0 = q[1], c0 = q[2], e0 = q[3];
         const float4 a1 = q[j], b1 = q[j + 1], c1 = q[j + 2], e1 = q[j + 3];
-        const TriEval E0 = eval_record(a0, b0, c0, e0, o, d);
-        const TriEval E1 = eval_record(a1, b1, c1, e1, o, d);
+        TriEval E0, E1;
+        eval_pair(a0, b0, c0, e0, a1, b1, c1, e1, o, d, E0, E1);
         fast_apply<MODE>(E0, first, qlen, F);
         if (n > 1) fast_apply<MODE>(E1, first + 1, qlen, F);
     } else {
