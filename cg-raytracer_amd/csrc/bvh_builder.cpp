@@ -221,8 +221,8 @@ struct SubBuilder {
         }
         for (int r = 0; r < 2; r++) {
             SubNode& N = nodes[me + r];
-            std::memcpy(N.box0, &box[2 * r], 24);
-            std::memcpy(N.box1, &box[2 * r + 1], 24);
+            sub_box_store(N.box0, box[2 * r]);
+            sub_box_store(N.box1, box[2 * r + 1]);
             N.ref0 = ref[2 * r];
             N.ref1 = ref[2 * r + 1];
             N.pad[0] = N.pad[1] = 0;
@@ -519,8 +519,8 @@ struct TopBuilder {
         }
         for (int r = 0; r < 2; r++) {
             SubNode& N = nodes[me + r];
-            std::memcpy(N.box0, &cbox[2 * r], 24);
-            std::memcpy(N.box1, &cbox[2 * r + 1], 24);
+            sub_box_store(N.box0, cbox[2 * r]);
+            sub_box_store(N.box1, cbox[2 * r + 1]);
             N.ref0 = cref[2 * r];
             N.ref1 = cref[2 * r + 1];
             N.pad[0] = N.pad[1] = 0;
@@ -561,7 +561,12 @@ void build_fast_tree(BuiltBvh& out, bool force, bool leaf_accel, int open) {
     std::vector<int> parent(out.nodes.size(), -1);
     for (size_t i = 0; i < out.nodes.size(); i++)
         if (!out.nodes[i].leaf) parent[out.nodes[i].child[0]] = parent[out.nodes[i].child[1]] = (int)i;
-    out.paths.assign(nleaves * PATH_BOXES * 6, 0.0f);
+    {  // unused slots hold all of space: every origin lies strictly inside, so such a box passes the certificate unread
+        const float inf = std::numeric_limits<float>::infinity();
+        const float all[6] = {-inf, -inf, -inf, inf, inf, inf};
+        out.paths.resize(nleaves * PATH_BOXES * 6);
+        for (size_t k = 0; k < nleaves * PATH_BOXES; k++) std::memcpy(&out.paths[k * 6], all, 24);
+    }
     for (size_t i = 0; i < out.nodes.size(); i++) {
         if (!out.nodes[i].leaf) continue;
         const uint32_t li = (uint32_t)out.node_to_ref_index[i];
@@ -591,9 +596,7 @@ void build_fast_tree(BuiltBvh& out, bool force, bool leaf_accel, int open) {
                 const float* cb[2] = {N.box0, N.box1};
                 for (int c = 0; c < 2; c++) {
                     if (cr[c] == REF_NONE) continue;
-                    Box6 bb;
-                    std::memcpy(&bb, cb[c], 24);
-                    b2.push_back(bb);
+                    b2.push_back(sub_box_load(cb[c]));
                     r2.push_back(cr[c]);
                 }
             }

@@ -40,6 +40,8 @@ static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
 // Half a node of a leaf's in-leaf accelerator or of the fast tree (DESIGN.md "In-leaf accelerator", "Certified walk"): two
 // child boxes inline (64 B); a node is two consecutive SubNodes, 128-byte aligned.  A child is another SubNode
 // (ref = index) or a run of 1..32 TriRecords (ref = REF_LEAF | (count - 1) << 26 | first record).
+// A child box is stored per axis as the pair {lower, upper}: {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z}, so that the two planes
+// of an axis are one operand of the packed FP32 pipe (walk_exact.h slab_cons).
 struct alignas(16) SubNode {
     float box0[6];
     float box1[6];
@@ -65,7 +67,8 @@ static const int TOP_MAX_DEPTH = 6;
 static_assert((1 << (2 * TOP_MAX_DEPTH)) >= (1 << (MAX_LEVELS - 1)), "the top tree must hold every reference leaf");
 static const int FAST_STACK_ENTRIES = (SUB_WIDTH - 1) * (TOP_MAX_DEPTH + SUB_MAX_DEPTH);
 static_assert(FAST_STACK_ENTRIES <= 2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES, "the fast walk's stack must fit the exact walk's LDS slice");
-static const int PATH_BOXES = MAX_LEVELS - 1;  // boxes per leaf in SceneDev::paths (6 floats each)
+static const int PATH_BOXES = (MAX_LEVELS - 1 + 1) & ~1;  // box slots per leaf in SceneDev::paths (6 floats each): the <= MAX_LEVELS - 1
+                                                         // boxes of the path, padded to an even count (read two at a time)
 
 // One triangle, everything the geometric test needs (64 B).  n and D are the ray-independent
 // trianglePlane (ray_tracing.cpp:74-82) evaluated once on the host with the reference's arithmetic.
@@ -95,6 +98,21 @@ struct SphereRecord {
 struct Box6 {
     float lo[3], hi[3];
 };
+// SubNode box slot <-> Box6
+inline void sub_box_store(float dst[6], const Box6& b) {
+    for (int a = 0; a < 3; a++) {
+        dst[2 * a] = b.lo[a];
+        dst[2 * a + 1] = b.hi[a];
+    }
+}
+inline Box6 sub_box_load(const float src[6]) {
+    Box6 b;
+    for (int a = 0; a < 3; a++) {
+        b.lo[a] = src[2 * a];
+        b.hi[a] = src[2 * a + 1];
+    }
+    return b;
+}
 
 // Everything a kernel needs, passed by value.
 struct SceneDev {

@@ -35,7 +35,7 @@ namespace cgrt {
 #if CGRT_MIN_WAVES > 0
 #define CGRT_LB __launch_bounds__(CGRT_BLOCK, CGRT_MIN_WAVES)
 #else
-#define CGRT_LB __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(1, CGRT_MAX_WAVES)))
+#define CGRT_LB __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(3, CGRT_MAX_WAVES)))
 #endif
 // Per-lane LDS stack, in 4-byte slots: a deferred reference child takes 2 slots (ref, tSecond), at most
 // MAX_LEVELS-1 of them; an in-leaf accelerator entry takes 1 slot (ref), at most SUB_STACK_ENTRIES.
@@ -71,8 +71,12 @@ __device__ __forceinline__ F3 ld3(const float* p) { return f3(p[0], p[1], p[2]);
 // at which something can be hit.  Rays outside the range where that argument holds (non-finite
 // components, |d|max or |o|max beyond 2^+-40, NaN t) are flagged irregular and test every triangle of a
 // leaf instead.  DESIGN.md "In-leaf accelerator" has the full argument.
+typedef float f2v __attribute__((ext_vector_type(2)));  // one operand of the packed FP32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 struct RayPre {
-    F3 inv, oin, oif;
+    F3 inv;
+    // per axis the addends of the {lower, upper} plane pair: -(o * inv + slack) for the plane the ray meets first,
+    // -(o * inv - slack) for the other one (which is which depends on the direction's sign)
+    f2v cx, cy, cz;
     bool sx, sy, sz;
     bool regular;
 };
@@ -96,19 +100,34 @@ __device__ __forceinline__ RayPre make_raypre(const SceneDev& S, const F3 o, con
     const float eps = S.scene_eps + 1.52587890625e-05f * omax;  // 2^-16
     const F3 oi = f3(o.x * P.inv.x, o.y * P.inv.y, o.z * P.inv.z);
     const F3 sl = f3(eps * fabsf(P.inv.x), eps * fabsf(P.inv.y), eps * fabsf(P.inv.z));
-    P.oin = f3(oi.x + sl.x, oi.y + sl.y, oi.z + sl.z);
-    P.oif = f3(oi.x - sl.x, oi.y - sl.y, oi.z - sl.z);
-    (void)omax;
+    const F3 oin = f3(oi.x + sl.x, oi.y + sl.y, oi.z + sl.z), oif = f3(oi.x - sl.x, oi.y - sl.y, oi.z - sl.z);
+    P.cx = P.sx ? (f2v){-oif.x, -oin.x} : (f2v){-oin.x, -oif.x};
+    P.cy = P.sy ? (f2v){-oif.y, -oin.y} : (f2v){-oin.y, -oif.y};
+    P.cz = P.sz ? (f2v){-oif.z, -oin.z} : (f2v){-oin.z, -oif.z};
     return P;
 }
 
-// Conservative [tn, tf] of the widened box; explicit fma: this is NOT reference arithmetic.
-__device__ __forceinline__ void slab_cons(const RayPre& P, const F3 lo, const F3 hi, float& tn, float& tf) {
-    const float nx = P.sx ? hi.x : lo.x, fx = P.sx ? lo.x : hi.x;
-    const float ny = P.sy ? hi.y : lo.y, fy = P.sy ? lo.y : hi.y;
-    const float nz = P.sz ? hi.z : lo.z, fz = P.sz ? lo.z : hi.z;
-    tn = fmaxf(fmaxf(__builtin_fmaf(nx, P.inv.x, -P.oin.x), __builtin_fmaf(ny, P.inv.y, -P.oin.y)), __builtin_fmaf(nz, P.inv.z, -P.oin.z));
-    tf = fminf(fminf(__builtin_fmaf(fx, P.inv.x, -P.oif.x), __builtin_fmaf(fy, P.inv.y, -P.oif.y)), __builtin_fmaf(fz, P.inv.z, -P.oif.z));
+// Conservative [tn, tf] of the widened box whose planes come as per-axis {lower, upper} pairs (SubNode's layout): one
+// packed fma per axis, then the entry / exit plane picked by the direction's sign.  Explicit fma: this is NOT reference
+// arithmetic.
+__device__ __forceinline__ void slab_cons(const RayPre& P, const f2v bx, const f2v by, const f2v bz, float& tn, float& tf) {
+    const f2v tx = __builtin_elementwise_fma(bx, (f2v){P.inv.x, P.inv.x}, P.cx);
+    const f2v ty = __builtin_elementwise_fma(by, (f2v){P.inv.y, P.inv.y}, P.cy);
+    const f2v tz = __builtin_elementwise_fma(bz, (f2v){P.inv.z, P.inv.z}, P.cz);
+    const float nx = P.sx ? tx.y : tx.x, fx = P.sx ? tx.x : tx.y;
+    const float ny = P.sy ? ty.y : ty.x, fy = P.sy ? ty.x : ty.y;
+    const float nz = P.sz ? tz.y : tz.x, fz = P.sz ? tz.x : tz.y;
+    tn = fmaxf(fmaxf(nx, ny), nz);
+    tf = fminf(fminf(fx, fy), fz);
+}
+// the four children of a 128-byte node held in six 16-byte quarters (cgrt_layout.h SubNode: per child x, y, z pairs)
+__device__ __forceinline__ void slab_cons4(const RayPre& P, const float4 a0, const float4 b0, const float4 c0, const float4 a1, const float4 b1,
+                                           const float4 c1, float& tn0, float& tf0, float& tn1, float& tf1, float& tn2, float& tf2, float& tn3,
+                                           float& tf3) {
+    slab_cons(P, (f2v){a0.x, a0.y}, (f2v){a0.z, a0.w}, (f2v){b0.x, b0.y}, tn0, tf0);
+    slab_cons(P, (f2v){b0.z, b0.w}, (f2v){c0.x, c0.y}, (f2v){c0.z, c0.w}, tn1, tf1);
+    slab_cons(P, (f2v){a1.x, a1.y}, (f2v){a1.z, a1.w}, (f2v){b1.x, b1.y}, tn2, tf2);
+    slab_cons(P, (f2v){b1.z, b1.w}, (f2v){c1.x, c1.y}, (f2v){c1.z, c1.w}, tn3, tf3);
 }
 
 // State of one reference leaf's scan, order-free form (see bvh_builder.cpp "In-leaf accelerator"):
@@ -185,7 +204,6 @@ __device__ __forceinline__ TriEval eval_record(const float4 a, const float4 b, c
 #ifndef CGRT_PACKED_PAIR
 #define CGRT_PACKED_PAIR 1
 #endif
-typedef float f2v __attribute__((ext_vector_type(2)));
 struct P3 {
     f2v x, y, z;
 };
@@ -328,7 +346,7 @@ __device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P
 #endif
 #ifdef CGRT_EXP_EXTRA_VALU  // experiment only: CGRT_EXP_EXTRA_VALU additional fma per node step
         {
-            float x0 = P.inv.x, x1 = P.inv.y, x2 = P.inv.z, x3 = P.oin.x;
+            float x0 = P.inv.x, x1 = P.inv.y, x2 = P.inv.z, x3 = P.cx.x;
 #pragma unroll
             for (int i = 0; i < CGRT_EXP_EXTRA_VALU / 4; i++) {
                 x0 = __builtin_fmaf(x0, a0.x, x1);
@@ -340,10 +358,7 @@ __device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P
         }
 #endif
         float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
-        slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
-        slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);
-        slab_cons(P, f3(a1.x, a1.y, a1.z), f3(a1.w, b1.x, b1.y), tn2, tf2);
-        slab_cons(P, f3(b1.z, b1.w, c1.x), f3(c1.y, c1.z, c1.w), tn3, tf3);
+        slab_cons4(P, a0, b0, c0, a1, b1, c1, tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3);
         // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
         // ignores ray.t altogether (ray_tracing.cpp:43-47) and its box contains the origin (tn < 0).
         const float tc = fmaxf(best_t, 0.0f);

@@ -86,20 +86,19 @@ template <bool COUNT>
 __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W, const uint32_t rec, const float t, LaneCounters& cnt) {
     const uint32_t leaf = S.tri_leaf[rec - S.tri_base];
     const uint32_t n = S.leaves[leaf].path_len;
-    const float2* pb = reinterpret_cast<const float2*>(S.paths + (size_t)leaf * (PATH_BOXES * 6));
+    // two boxes (48 B = three 16-byte loads) per round; the slot after an odd path holds an all-space box (origin strictly
+    // inside: passes whatever the ray), bvh_builder.cpp
+    const float4* pb = reinterpret_cast<const float4*>(S.paths + (size_t)leaf * (PATH_BOXES * 6));
     if (COUNT) cnt.cert += n;
     const RayFast R = make_rayfast(S, W.o, W.d);  // (recomputed here rather than kept in registers through the search)
     bool ok = true;
-    for (uint32_t i = 0; i < n; i++) {
-        const float2 a = pb[3 * i], b = pb[3 * i + 1], c = pb[3 * i + 2];
+    // One box: the geometric part of the box test with the reference's arithmetic (t = +inf: no `cur >= ray.t` rejection), then
+    // cur <= t: see the header -- every ray.t the reference can hold before it accepts T is strictly above t
+    // (a NaN parameter -- 0 / 0 on a zero direction component -- is never rejected by `cur >= ray.t`, nor skipped on pop by
+    // `ray.t < tSecond`: !(tb > t) says the same)
+    auto entered = [&](const F3 lo, const F3 hi) __attribute__((always_inline)) -> bool {
         float tb;
-        bool inside;
-        // the geometric part of the box test with the reference's arithmetic (t = +inf: no `cur >= ray.t` rejection), then
-        // cur <= t: see the header -- every ray.t the reference can hold before it accepts T is strictly above t
-        // (a NaN parameter -- 0 / 0 on a zero direction component -- is never rejected by `cur >= ray.t`, nor skipped on pop by
-        // `ray.t < tSecond`: !(tb > t) says the same)
-        const F3 lo = f3(a.x, a.y, b.x), hi = f3(b.y, c.x, c.y);
-        bool geom;
+        bool inside, geom;
         if (R.fd) {
             geom = ray_box_fast<true>(lo, hi, W.o, W.d, R, __builtin_inff(), tb, inside);
         } else {  // outside the exact fast division's envelope: the reference's test as written (IEEE divisions, ternary ladders)
@@ -107,7 +106,14 @@ __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W,
             geom = ray_box(lo, hi, W.o, W.d, __builtin_inff(), tb);
             inside = starts_in_box(W.o, lo, hi);
         }
-        ok = ok && (inside || (geom && !(tb > t)));
+        return inside || (geom && !(tb > t));
+    };
+    for (uint32_t i = 0; i < n; i += 2) {
+        const float4 a = pb[0], b = pb[1], c = pb[2];
+        pb += 3;
+        const bool e0 = entered(f3(a.x, a.y, a.z), f3(a.w, b.x, b.y));
+        const bool e1 = entered(f3(b.z, b.w, c.x), f3(c.y, c.z, c.w));
+        ok = ok && e0 && e1;
     }
     return ok;
 }
@@ -174,8 +180,9 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
     // the owner's ray, broadcast to its quad (all 64 lanes take part in the shuffles)
     RayPre P;
     P.inv = f3(__shfl(W.P.inv.x, src, 64), __shfl(W.P.inv.y, src, 64), __shfl(W.P.inv.z, src, 64));
-    P.oin = f3(__shfl(W.P.oin.x, src, 64), __shfl(W.P.oin.y, src, 64), __shfl(W.P.oin.z, src, 64));
-    P.oif = f3(__shfl(W.P.oif.x, src, 64), __shfl(W.P.oif.y, src, 64), __shfl(W.P.oif.z, src, 64));
+    P.cx = (f2v){__shfl(W.P.cx.x, src, 64), __shfl(W.P.cx.y, src, 64)};
+    P.cy = (f2v){__shfl(W.P.cy.x, src, 64), __shfl(W.P.cy.y, src, 64)};
+    P.cz = (f2v){__shfl(W.P.cz.x, src, 64), __shfl(W.P.cz.y, src, 64)};
     const int sg = __shfl((int)((W.P.sx ? 1 : 0) | (W.P.sy ? 2 : 0) | (W.P.sz ? 4 : 0)), src, 64);
     P.sx = (sg & 1) != 0;
     P.sy = (sg & 2) != 0;
@@ -222,10 +229,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
             const float4 a1 = g[4], b1 = g[5], c1 = g[6];
             const uint2 m1 = *reinterpret_cast<const uint2*>(g + 7);
             float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
-            slab_cons(P, f3(a0.x, a0.y, a0.z), f3(a0.w, b0.x, b0.y), tn0, tf0);
-            slab_cons(P, f3(b0.z, b0.w, c0.x), f3(c0.y, c0.z, c0.w), tn1, tf1);
-            slab_cons(P, f3(a1.x, a1.y, a1.z), f3(a1.w, b1.x, b1.y), tn2, tf2);
-            slab_cons(P, f3(b1.z, b1.w, c1.x), f3(c1.y, c1.z, c1.w), tn3, tf3);
+            slab_cons4(P, a0, b0, c0, a1, b1, c1, tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3);
             const float tc = fmaxf(G.best_t, 0.0f);
             float k0 = ((tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc)) ? tn0 : inf;
             float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
@@ -384,7 +388,11 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, 
         if (__any(eligible)) certified = walk_fast_wave<COUNT, MODE>(S, eligible, W, qlen, wave_stk, s_map, cnt);
         if (COUNT && eligible && !certified) cnt.fallback++;
     }
+#ifdef CGRT_EXP_NO_FALLBACK  // experiment only (wrong results for uncertified rays): register budget of the search alone
+    if (entered && !certified && !FAST) {
+#else
     if (entered && !certified) {
+#endif
         if (FAST) {  // (the per-ray constants of the exact walk are rebuilt rather than kept alive through the search)
             W.P = make_raypre(S, W.o, W.d, W.t);
             W.R = make_rayfast(S, W.o, W.d);
