@@ -868,6 +868,11 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         for (uint32_t* r : {&N.ref0, &N.ref1})
             if (*r != REF_NONE) *r += (*r & REF_LEAF) ? out.tri_base : out.sub_base;
     if (out.fast_root != REF_NONE) out.fast_root += (out.fast_root & REF_LEAF) ? out.tri_base : out.sub_base;
+    // the device reads all four child references of a node with ONE 16-byte load: the first half's last quarter
+    for (size_t i = 0; i + 1 < out.subnodes.size(); i += 2) {
+        out.subnodes[i].pad[0] = out.subnodes[i + 1].ref0;
+        out.subnodes[i].pad[1] = out.subnodes[i + 1].ref1;
+    }
     out.root_box = out.nodes[0].box;
     out.root_ref = ref_of(0);
     if (!out.subnodes.empty()) {
@@ -877,7 +882,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
             const uint32_t li = r & ~REF_LEAF;
             const uint32_t root = out.leaves[li].sub_root;
             if (root == REF_NONE) return r;
-            out.subnodes[root - out.sub_base].pad[0] = li;
+            out.subnodes[root - out.sub_base + 1].pad[0] = li;  // (second half: the first half's pad words carry references)
             return REF_LEAF | REF_LEAF_ACCEL | root;
         };
         for (NodePacket& P : out.packets) {

@@ -440,7 +440,7 @@ int cgrt_debug_check_layout(CgrtScene* s) {
         if (r & REF_LEAF_ACCEL) {
             const uint32_t root = r & REF_INDEX26;
             if (root < B.sub_base || root >= B.tri_base || ((root - B.sub_base) & 1u)) return false;
-            li = B.subnodes[root - B.sub_base].pad[0];
+            li = B.subnodes[root - B.sub_base + 1].pad[0];
             if (li >= nleaf || B.leaves[li].sub_root != root) return false;
         } else {
             li = r & ~REF_LEAF;
@@ -535,7 +535,7 @@ int cgrt_debug_check_layout(CgrtScene* s) {
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes) {
     if (node_bytes) *node_bytes = sizeof(NodePacket);
     if (tri_bytes) *tri_bytes = sizeof(TriRecord);
-    if (sub_bytes) *sub_bytes = sizeof(SubNode) * 2;  // bytes read per accelerator node visit
+    if (sub_bytes) *sub_bytes = sizeof(SubNode) * 2 - 16;  // bytes read per accelerator node visit: four boxes (96 B) + four references (16 B)
     if (hit_bytes) *hit_bytes = sizeof(CgrtHit);
 }
 

@@ -10,7 +10,7 @@ static const uint32_t REF_LEAF = 0x80000000u;
 static const uint32_t REF_NONE = 0xffffffffu;
 // A leaf with an in-leaf accelerator is referenced by the accelerator's root directly: REF_LEAF | REF_LEAF_ACCEL | index
 // of the root SubNode in the record array (26 bits), so that entering the leaf needs no LeafRec load; the leaf-table
-// index of such a leaf is kept in its root SubNode's pad[0] for the paths that want first/count (linear scan).
+// index of such a leaf is kept in pad[0] of its root node's SECOND SubNode for the paths that want first/count (linear scan).
 static const uint32_t REF_LEAF_ACCEL = 0x40000000u;
 static const uint32_t REF_INDEX26 = 0x03ffffffu;
 static const int MAX_LEVELS = 12;  // bvh.cpp:48 maxDepth; per-ray stack never exceeds MAX_LEVELS - 1
@@ -42,6 +42,9 @@ static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
 // (ref = index) or a run of 1..32 TriRecords (ref = REF_LEAF | (count - 1) << 26 | first record).
 // A child box is stored per axis as the pair {lower, upper}: {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z}, so that the two planes
 // of an axis are one operand of the packed FP32 pipe (walk_exact.h slab_cons).
+// In the FIRST half of a node pad[0], pad[1] repeat the second half's ref0, ref1, so that the device reads the four child
+// references with one 16-byte load (7 loads per node step instead of 8); in the second half pad[0] carries the leaf index
+// of an accelerator root (REF_LEAF_ACCEL).
 struct alignas(16) SubNode {
     float box0[6];
     float box1[6];

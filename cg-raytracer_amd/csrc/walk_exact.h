@@ -69,7 +69,7 @@ __device__ __forceinline__ F3 ld3(const float* p) { return f3(p[0], p[1], p[2]);
 // -- 256x the rounding unit at the magnitudes involved -- and zero/tiny direction components are
 // clamped away from zero (2^-40 relative), which moves the ray by far less than eps over any distance
 // at which something can be hit.  Rays outside the range where that argument holds (non-finite
-// components, |d|max or |o|max beyond 2^+-40, NaN t) are flagged irregular and test every triangle of a
+// components, |d|max or |o|max beyond 2^+-40, NaN t, a slack that would be denormal) are flagged irregular and test every triangle of a
 // leaf instead.  DESIGN.md "In-leaf accelerator" has the full argument.
 typedef float f2v __attribute__((ext_vector_type(2)));  // one operand of the packed FP32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 struct RayPre {
@@ -88,7 +88,9 @@ __device__ __forceinline__ RayPre make_raypre(const SceneDev& S, const F3 o, con
     const float big = 1.099511627776e12f, small = 9.094947017729282e-13f;  // 2^40, 2^-40
     const bool finite = (fabsf(o.x) <= big) && (fabsf(o.y) <= big) && (fabsf(o.z) <= big) && (fabsf(d.x) <= big) &&
                         (fabsf(d.y) <= big) && (fabsf(d.z) <= big);  // false for NaN and +-inf too
-    P.regular = finite && (dmax >= small) && !(t != t) && (S.scene_eps <= 16777216.0f);
+    const float eps = S.scene_eps + 1.52587890625e-05f * omax;  // 2^-16
+    // eps >= 2^-60 keeps the slack eps * |inv| (|inv| >= 2^-40) far above the denormals' absolute rounding error
+    P.regular = finite && (dmax >= small) && !(t != t) && (S.scene_eps <= 16777216.0f) && (eps >= 8.673617379884035e-19f);
     const float fl = dmax * small;
     const float dx = fabsf(d.x) >= fl ? d.x : copysignf(fl, d.x);
     const float dy = fabsf(d.y) >= fl ? d.y : copysignf(fl, d.y);
@@ -97,7 +99,6 @@ __device__ __forceinline__ RayPre make_raypre(const SceneDev& S, const F3 o, con
     P.sx = dx < 0;
     P.sy = dy < 0;
     P.sz = dz < 0;
-    const float eps = S.scene_eps + 1.52587890625e-05f * omax;  // 2^-16
     const F3 oi = f3(o.x * P.inv.x, o.y * P.inv.y, o.z * P.inv.z);
     const F3 sl = f3(eps * fabsf(P.inv.x), eps * fabsf(P.inv.y), eps * fabsf(P.inv.z));
     const F3 oin = f3(oi.x + sl.x, oi.y + sl.y, oi.z + sl.z), oif = f3(oi.x - sl.x, oi.y - sl.y, oi.z - sl.z);
@@ -327,36 +328,8 @@ __device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P
         }
         const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
         const float4 a0 = q[0], b0 = q[1], c0 = q[2];
-        const uint2 m0 = *reinterpret_cast<const uint2*>(q + 3);
+        const uint4 m = *reinterpret_cast<const uint4*>(q + 3);  // the four child references (cgrt_layout.h SubNode)
         const float4 a1 = q[4], b1 = q[5], c1 = q[6];
-        const uint2 m1 = *reinterpret_cast<const uint2*>(q + 7);
-#ifdef CGRT_EXP_EXTRA_LOADS  // experiment only: re-read quarters of the same record (L1 hits) to load the memory pipe
-        {
-            int z;  // an opaque zero: plain (L1-cached) loads the compiler cannot merge with the real ones
-            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-            const float4* vq = q + z;
-            float acc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < CGRT_EXP_EXTRA_LOADS; i++) {
-                const float4 x = vq[i < 3 ? i : i + 1];
-                acc += x.x;
-            }
-            if (acc == 1.2345e-30f) sp = 0;
-        }
-#endif
-#ifdef CGRT_EXP_EXTRA_VALU  // experiment only: CGRT_EXP_EXTRA_VALU additional fma per node step
-        {
-            float x0 = P.inv.x, x1 = P.inv.y, x2 = P.inv.z, x3 = P.cx.x;
-#pragma unroll
-            for (int i = 0; i < CGRT_EXP_EXTRA_VALU / 4; i++) {
-                x0 = __builtin_fmaf(x0, a0.x, x1);
-                x1 = __builtin_fmaf(x1, a0.y, x2);
-                x2 = __builtin_fmaf(x2, a0.z, x3);
-                x3 = __builtin_fmaf(x3, a0.w, x0);
-            }
-            if ((x0 + x1) + (x2 + x3) == 1.2345e-30f) sp = 0;
-        }
-#endif
         float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
         slab_cons4(P, a0, b0, c0, a1, b1, c1, tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3);
         // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
@@ -368,7 +341,7 @@ __device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P
         float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
         float k2 = ((tn2 <= tf2) && (tf2 >= 0.0f) && (tn2 <= tc)) ? tn2 : inf;
         float k3 = ((tn3 <= tf3) && (tf3 >= 0.0f) && (tn3 <= tc)) ? tn3 : inf;
-        uint32_t r0 = m0.x, r1 = m0.y, r2 = m1.x, r3 = m1.y;
+        uint32_t r0 = m.x, r1 = m.y, r2 = m.z, r3 = m.w;
 #define CGRT_CSWAP(ka, ra, kb, rb)          \
 {                                       \
     const bool sw = kb < ka;            \
@@ -614,7 +587,7 @@ __device__ __forceinline__ bool topo_pop(const float t, uint32_t& cur, int& sp, 
 
 // LeafRec of a leaf reference in either encoding (cgrt_layout.h REF_LEAF_ACCEL).
 __device__ __forceinline__ LeafRec leaf_rec_of(const SceneDev& S, const uint32_t ref) {
-    const uint32_t li = (ref & REF_LEAF_ACCEL) ? S.subnodes[ref & REF_INDEX26].pad[0] : (ref & ~REF_LEAF);
+    const uint32_t li = (ref & REF_LEAF_ACCEL) ? S.subnodes[(ref & REF_INDEX26) + 1u].pad[0] : (ref & ~REF_LEAF);
     return S.leaves[li];
 }
 // "One loop" form of the same walk: an iteration offers every lane, in this order, two topology steps (pops included),

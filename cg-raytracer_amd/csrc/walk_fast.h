@@ -225,9 +225,8 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
             }
             const float4* g = reinterpret_cast<const float4*>(S.subnodes + ref);
             const float4 a0 = g[0], b0 = g[1], c0 = g[2];
-            const uint2 m0 = *reinterpret_cast<const uint2*>(g + 3);
+            const uint4 m = *reinterpret_cast<const uint4*>(g + 3);
             const float4 a1 = g[4], b1 = g[5], c1 = g[6];
-            const uint2 m1 = *reinterpret_cast<const uint2*>(g + 7);
             float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
             slab_cons4(P, a0, b0, c0, a1, b1, c1, tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3);
             const float tc = fmaxf(G.best_t, 0.0f);
@@ -235,7 +234,7 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
             float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
             float k2 = ((tn2 <= tf2) && (tf2 >= 0.0f) && (tn2 <= tc)) ? tn2 : inf;
             float k3 = ((tn3 <= tf3) && (tf3 >= 0.0f) && (tn3 <= tc)) ? tn3 : inf;
-            r0 = m0.x, r1 = m0.y, r2 = m1.x, r3 = m1.y;
+            r0 = m.x, r1 = m.y, r2 = m.z, r3 = m.w;
 #define CGRT_CSWAP(ka, ra, kb, rb)          \
 {                                       \
     const bool sw = kb < ka;            \
@@ -388,11 +387,7 @@ __device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, 
         if (__any(eligible)) certified = walk_fast_wave<COUNT, MODE>(S, eligible, W, qlen, wave_stk, s_map, cnt);
         if (COUNT && eligible && !certified) cnt.fallback++;
     }
-#ifdef CGRT_EXP_NO_FALLBACK  // experiment only (wrong results for uncertified rays): register budget of the search alone
-    if (entered && !certified && !FAST) {
-#else
     if (entered && !certified) {
-#endif
         if (FAST) {  // (the per-ray constants of the exact walk are rebuilt rather than kept alive through the search)
             W.P = make_raypre(S, W.o, W.d, W.t);
             W.R = make_rayfast(S, W.o, W.d);
