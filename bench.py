@@ -294,7 +294,7 @@ def main():
                 "roofline": {
                     "bound": "hbm",
                     "bound_note": "classification of SURVEY.md 8(d); the profiles show the kernel latency/issue-bound: physical HBM traffic is a few % of the "
-                                  "algorithmic bytes (records are re-read through L1/L2/Infinity Cache) -- see hbm_physical_frac",
+                                  "algorithmic bytes (records are re-read through L1/L2/Infinity Cache), so frac can pass 1.0 on large frames -- see hbm_physical_frac",
                     "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
