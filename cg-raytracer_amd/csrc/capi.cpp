@@ -551,6 +551,9 @@ struct LaneGuard {
     explicit LaneGuard(CgrtScene* s) : sc(s) {}
     ~LaneGuard() {
         if (!L) return;
+        // An entry that returns early (an error after work was queued) must not leave copies in flight into its caller's
+        // memory or hand a busy lane's staging buffers to the next caller: a finished stream answers the query at once.
+        if (hipSetDevice(sc->device) == hipSuccess && hipStreamQuery(L->stream) != hipSuccess) (void)hipStreamSynchronize(L->stream);
         std::lock_guard<std::mutex> lk(sc->lanes_mutex);
         sc->lanes_free.push_back(L);
     }
