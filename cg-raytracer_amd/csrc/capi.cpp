@@ -155,7 +155,11 @@ struct CgrtScene {
     uint32_t fast_root = REF_NONE;  // the scene's fast tree (REF_NONE: none); dev.fast_root is this or REF_NONE by cgrt_scene_set_walk
     uint32_t nmesh = 0;
     unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, reset by every launch
-    std::atomic<unsigned> launch_seq{0};
+    // the persistent kernel's launches take the queue blocks in turn; a block is handed to a new launch only behind the
+    // launch that used it last (an event per block), so any number of frames may be in flight on any streams
+    std::mutex queue_mutex;
+    unsigned launch_seq = 0;
+    hipEvent_t queue_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // Host-pointer entries (cgrt_intersect_batch, cgrt_trace_primary, cgrt_count_*, ...) run on "call lanes": a private
     // stream + device scratch + pinned staging + a counter block, taken from this pool for the duration of one call and
     // kept afterwards.  Concurrent callers (the reference calls intersect from an omp parallel for, main.cpp:653-656) get
@@ -195,6 +199,8 @@ struct CgrtScene {
         }
         for (WorkSlot& w : work)
             if (w.p) (void)hipFree(w.p);
+        for (hipEvent_t e : queue_done)
+            if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -711,8 +717,15 @@ int cgrt_intersect_brute_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, in
 static int launch_primary(CgrtScene* s, const CameraDev& C, const FrameDev& F, CgrtHitDev* d_hits, float* d_normals, unsigned long long* counters,
                           hipStream_t stream) {
     if (g_primary_mode.load() == 1) {
-        unsigned int* q = s->d_queues + CGRT_QUEUE_BLOCK_WORDS * (s->launch_seq.fetch_add(1) & 7u);
+        std::lock_guard<std::mutex> lk(s->queue_mutex);
+        const unsigned k = s->launch_seq++ & 7u;
+        unsigned int* q = s->d_queues + CGRT_QUEUE_BLOCK_WORDS * k;
+        if (s->queue_done[k])
+            HIP_TRY(hipStreamWaitEvent(stream, s->queue_done[k], 0));  // the block's previous launch, on whatever stream it ran
+        else
+            HIP_TRY(hipEventCreateWithFlags(&s->queue_done[k], hipEventDisableTiming));
         HIP_TRY(launch_trace_primary_persistent(s->dev, C, F, d_hits, d_normals, counters, q, s->persistent_blocks, stream));
+        HIP_TRY(hipEventRecord(s->queue_done[k], stream));
     } else {
         HIP_TRY(launch_trace_primary(s->dev, C, F, d_hits, d_normals, counters, stream));
     }

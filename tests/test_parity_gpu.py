@@ -378,6 +378,37 @@ def test_persistent_kernel_same_results(pkg, orc, W, H, nranks):
         pkg.set_primary_mode(0)
 
 
+def test_persistent_kernel_many_frames_in_flight(pkg):
+    """More launches in flight than the persistent kernel has queue blocks (8): twelve host threads trace the same frame
+    at once, each on its call lane's private stream.  A block is reused only behind the launch that had it last, so
+    every frame must come out like the one-wave-per-tile frame."""
+    import threading
+
+    W, H = 320, 200
+    sd = pkg.scenes.make_dragon(40_000)
+    cam = pkg.scenes.default_camera(W, H)
+    sc = pkg.Scene(sd)
+    h0, _ = sc.trace_primary(cam, W, H)
+    bad = []
+
+    def work():
+        for _ in range(4):
+            h1, _ = sc.trace_primary(cam, W, H)
+            if h1.tobytes() != h0.tobytes():
+                bad.append(1)
+
+    try:
+        pkg.set_primary_mode(1)
+        threads = [threading.Thread(target=work) for _ in range(12)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        pkg.set_primary_mode(0)
+    assert not bad, f"{len(bad)} of 48 concurrent persistent frames differ"
+
+
 def test_counters_match_oracle_replay(pkg, orc):
     """cgrt_count_* (instrumented launch) == the oracle's count of the same traversal: the reference tree is
     walked node for node like the reference does; with the in-leaf accelerator off the triangle tests match
