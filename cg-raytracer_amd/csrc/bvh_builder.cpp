@@ -572,8 +572,18 @@ void build_fast_tree(BuiltBvh& out, bool force, bool leaf_accel, int open) {
         const uint32_t li = (uint32_t)out.node_to_ref_index[i];
         int chain[MAX_LEVELS], n = 0;
         for (int k = (int)i; parent[k] >= 0; k = parent[k]) chain[n++] = k;  // the root (no parent) is not part of the path
-        out.leaves[li].path_len = (uint32_t)n;
         for (int k = 0; k < n; k++) std::memcpy(&out.paths[((size_t)li * PATH_BOXES + k) * 6], &out.nodes[chain[n - 1 - k]].box, 24);
+        // Boxes a certificate has to test explicitly (walk_fast.h path_certified): the leaf's own, and every box that does
+        // not contain the next one down.  A box that contains a box the ray provably enters at t is entered at t too (the
+        // reference's slab arithmetic is monotone in the plane coordinates), so nested ancestors need no test of their own.
+        uint32_t need = n ? (1u << (n - 1)) : 0u;
+        for (int k = 0; k + 1 < n; k++) {
+            const Box6 &a = out.nodes[chain[n - 1 - k]].box, &b = out.nodes[chain[n - 2 - k]].box;  // a: level k, b: its child on the path
+            bool nested = true;
+            for (int ax = 0; ax < 3; ax++) nested = nested && (a.lo[ax] <= b.lo[ax]) && (a.hi[ax] >= b.hi[ax]);
+            if (!nested) need |= 1u << k;
+        }
+        out.leaves[li].path_len = (uint32_t)n | (need << 8);
     }
     out.tri_leaf.resize(out.tris.size());
     for (uint32_t li = 0; li < nleaves; li++)

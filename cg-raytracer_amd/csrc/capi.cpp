@@ -528,9 +528,18 @@ int cgrt_debug_check_layout(CgrtScene* s) {
             if (!B.nodes[i].leaf) continue;
             const uint32_t li = (uint32_t)B.node_to_ref_index[i];
             const LeafRec& L = B.leaves[li];
-            if ((int)L.path_len != B.nodes[i].level) return fail(CGRT_E_ARG, "path length != leaf level");
-            if (L.path_len && std::memcmp(&B.paths[((size_t)li * PATH_BOXES + L.path_len - 1) * 6], &B.nodes[i].box, 24) != 0)
+            const uint32_t plen = L.path_len & 0xffu, need = L.path_len >> 8;
+            if ((int)plen != B.nodes[i].level) return fail(CGRT_E_ARG, "path length != leaf level");
+            if (plen && std::memcmp(&B.paths[((size_t)li * PATH_BOXES + plen - 1) * 6], &B.nodes[i].box, 24) != 0)
                 return fail(CGRT_E_ARG, "a path does not end in its leaf's box");
+            if (plen && (!(need & (1u << (plen - 1))) || (need >> plen))) return fail(CGRT_E_ARG, "a certificate must test its leaf's box and nothing beyond the path");
+            for (uint32_t k = 0; k + 1 < plen; k++) {  // a box the certificate skips contains the next one
+                if (need & (1u << k)) continue;
+                const float* a = &B.paths[((size_t)li * PATH_BOXES + k) * 6];
+                const float* b = a + 6;
+                for (int ax = 0; ax < 3; ax++)
+                    if (!(a[ax] <= b[ax] && a[3 + ax] >= b[3 + ax])) return fail(CGRT_E_ARG, "a skipped path box does not contain its successor");
+            }
             for (uint32_t k = 0; k < L.count; k++)
                 if (B.tri_leaf[L.first - B.tri_base + k] != li) return fail(CGRT_E_ARG, "tri_leaf does not match the leaf table");
         }

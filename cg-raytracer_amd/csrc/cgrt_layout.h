@@ -33,7 +33,8 @@ struct LeafRec {
     uint32_t first;  // first TriRecord
     uint32_t count;
     uint32_t sub_root;  // index of the leaf's first SubNode, REF_NONE when the leaf is scanned linearly
-    uint32_t path_len;  // boxes on the way from the root's child down to this leaf (its own box last): SceneDev::paths
+    uint32_t path_len;  // bits 0..7: boxes on the way from the root's child down to this leaf (its own box last): SceneDev::paths;
+                        // bits 8..: which of them a certificate tests explicitly (bit k = box k; the others contain their successor)
 };
 static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 B");
 

@@ -85,20 +85,29 @@ __device__ __forceinline__ void fast_test_run(const SceneDev& S, const uint32_t 
 template <bool COUNT>
 __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W, const uint32_t rec, const float t, LaneCounters& cnt) {
     const uint32_t leaf = S.tri_leaf[rec - S.tri_base];
-    const uint32_t n = S.leaves[leaf].path_len;
-    // two boxes (48 B = three 16-byte loads) per round; the slot after an odd path holds an all-space box (origin strictly
-    // inside: passes whatever the ray), bvh_builder.cpp
-    const float4* pb = reinterpret_cast<const float4*>(S.paths + (size_t)leaf * (PATH_BOXES * 6));
-    if (COUNT) cnt.cert += n;
+    const uint32_t pl = S.leaves[leaf].path_len;
+    const float2* pb = reinterpret_cast<const float2*>(S.paths + (size_t)leaf * (PATH_BOXES * 6));
     const RayFast R = make_rayfast(S, W.o, W.d);  // (recomputed here rather than kept in registers through the search)
+    // Inside RayFast::fd (finite operands, no zero direction component: no NaN, no infinity) a box that CONTAINS a box entered
+    // at t is entered at t as well: per axis fl(lo - o) and fl(x / d) are monotone in lo, so tIn can only fall and tOut only
+    // rise from the inner box to the outer one; then either tIn >= 0 and cur = tIn <= the inner box's, or tIn < 0 <= tOut, which
+    // puts the origin strictly inside the outer box unless it lies on one of its exit planes, where cur = tOut = 0.  The
+    // builder marks the boxes that do not contain their successor on the path (LeafRec::path_len bits 8..; the leaf's own
+    // box always): only those are tested.  Outside fd the ternary ladders see NaNs and every box is tested.
+    uint32_t need = R.fd ? (pl >> 8) : ((1u << (pl & 0xffu)) - 1u);
+    if (COUNT) cnt.cert += __popc(need);
     bool ok = true;
-    // One box: the geometric part of the box test with the reference's arithmetic (t = +inf: no `cur >= ray.t` rejection), then
-    // cur <= t: see the header -- every ray.t the reference can hold before it accepts T is strictly above t
-    // (a NaN parameter -- 0 / 0 on a zero direction component -- is never rejected by `cur >= ray.t`, nor skipped on pop by
-    // `ray.t < tSecond`: !(tb > t) says the same)
-    auto entered = [&](const F3 lo, const F3 hi) __attribute__((always_inline)) -> bool {
+    while (need) {
+        const uint32_t i = (uint32_t)__ffs((int)need) - 1u;
+        need &= need - 1u;
+        const float2 a = pb[3 * i], b = pb[3 * i + 1], c = pb[3 * i + 2];
+        const F3 lo = f3(a.x, a.y, b.x), hi = f3(b.y, c.x, c.y);
         float tb;
         bool inside, geom;
+        // the geometric part of the box test with the reference's arithmetic (t = +inf: no `cur >= ray.t` rejection), then
+        // cur <= t: see the header -- every ray.t the reference can hold before it accepts T is strictly above t
+        // (a NaN parameter -- 0 / 0 on a zero direction component -- is never rejected by `cur >= ray.t`, nor skipped on pop by
+        // `ray.t < tSecond`: !(tb > t) says the same)
         if (R.fd) {
             geom = ray_box_fast<true>(lo, hi, W.o, W.d, R, __builtin_inff(), tb, inside);
         } else {  // outside the exact fast division's envelope: the reference's test as written (IEEE divisions, ternary ladders)
@@ -106,14 +115,7 @@ __device__ __forceinline__ bool path_certified(const SceneDev& S, const Walk& W,
             geom = ray_box(lo, hi, W.o, W.d, __builtin_inff(), tb);
             inside = starts_in_box(W.o, lo, hi);
         }
-        return inside || (geom && !(tb > t));
-    };
-    for (uint32_t i = 0; i < n; i += 2) {
-        const float4 a = pb[0], b = pb[1], c = pb[2];
-        pb += 3;
-        const bool e0 = entered(f3(a.x, a.y, a.z), f3(a.w, b.x, b.y));
-        const bool e1 = entered(f3(b.z, b.w, c.x), f3(c.y, c.z, c.w));
-        ok = ok && e0 && e1;
+        ok = ok && (inside || (geom && !(tb > t)));
     }
     return ok;
 }
