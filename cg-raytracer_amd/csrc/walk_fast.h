@@ -17,8 +17,10 @@
 // The certificate is therefore: a strict unique minimum (any equal-t acceptance anywhere -> not certified), no
 // origin-on-plane acceptance anywhere (ray_tracing.cpp:43-47 has no t < ray.t guard: visit order decides), and
 // inside-or-(exact box test with cur <= t*) for the <= 11 boxes of T*'s path (SceneDev::paths) -- the reference's own arithmetic
-// (ray_box_fast, exact quotients).  A ray that is not certified is simply walked by walk_tree_unified: the certified walk
-// can only be slower, never different.  F4's false misses fail a path box and take that route.
+// (ray_box_fast, exact quotients) -- of which only those that do not contain their successor on the path need the test
+// (path_certified: a box containing an entered box is entered; in practice the leaf's own box alone).  A ray that is not
+// certified is simply walked by walk_tree_unified: the certified walk can only be slower, never different.  F4's false misses
+//  fail a path box and take that route.
 //
 // The search itself runs on the fast tree (bvh_builder.cpp build_fast_tree): 4-wide nodes over the reference leaves, then
 // the leaves' own accelerators, conservative slab tests only (slab_cons, the argument of walk_exact.h RayPre), any order.
