@@ -3,7 +3,7 @@
 name=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$name -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/$name.err
+rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$name -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/$name.err
 python3 - <<PY
 import csv, collections
 rows=list(csv.DictReader(open("$R/gpurun_out/$name/p_counter_collection.csv")))
