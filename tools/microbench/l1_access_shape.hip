@@ -41,6 +41,21 @@ __global__ __launch_bounds__(64) void k_shape(const float4* __restrict__ pool, u
                     v[k] = make_float4(t, 0.0f, 0.0f, 0.0f);
                 }
             }
+        } else if (MODE == 6) {
+            // every lane reads the SAME record with vector loads (the top levels of a coherent wave): one line, 1 KB delivered
+            const unsigned r = hash32(wave * 64u + 0x9e3779b9u * (unsigned)it) & nrec_mask;
+            const float4* p = pool + (size_t)r * 8;
+            unsigned zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));  // keeps the address in vector registers: vector loads, not scalar ones
+            p += zero;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = p[k];
+        } else if (MODE == 7) {
+            // the same record through the scalar cache (uniform address -> s_load), then used by every lane
+            const unsigned r = __builtin_amdgcn_readfirstlane(hash32(wave * 64u + 0x9e3779b9u * (unsigned)it) & nrec_mask);
+            const float4* p = pool + (size_t)r * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = p[k];
         } else if (MODE == 4 || MODE == 5) {
             // controls: 4 = the whole wave reads 256 contiguous bytes (4 B per lane, two lines) of a random record pair;
             //           5 = eight lanes per record like mode 1, but 4 B per lane (eight lines, 32 B each)
@@ -82,7 +97,7 @@ int main(int argc, char** argv) {
     for (unsigned nrec : {64u, 32768u, 1048576u}) {  // 8 KB, 4 MB, 128 MB pools
         float4* pool; hipMalloc(&pool, (size_t)nrec * 128);
         hipMemset(pool, 0, (size_t)nrec * 128);
-        for (int mode = 0; mode < 6; mode++) {
+        for (int mode = 0; mode < 8; mode++) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             for (int rep = 0; rep < 2; rep++) {
                 hipEventRecord(e0, nullptr);
@@ -91,15 +106,17 @@ int main(int argc, char** argv) {
                 else if (mode == 2) hipLaunchKernelGGL(k_shape<2>, dim3(blocks), dim3(64), 0, nullptr, pool, nrec - 1, iters, out);
                 else if (mode == 3) hipLaunchKernelGGL(k_shape<3>, dim3(blocks), dim3(64), 0, nullptr, pool, nrec - 1, iters, out);
                 else if (mode == 4) hipLaunchKernelGGL(k_shape<4>, dim3(blocks), dim3(64), 0, nullptr, pool, nrec - 1, iters, out);
-                else hipLaunchKernelGGL(k_shape<5>, dim3(blocks), dim3(64), 0, nullptr, pool, nrec - 1, iters, out);
+                else if (mode == 5) hipLaunchKernelGGL(k_shape<5>, dim3(blocks), dim3(64), 0, nullptr, pool, nrec - 1, iters, out);
+                else if (mode == 6) hipLaunchKernelGGL(k_shape<6>, dim3(blocks), dim3(64), 0, nullptr, pool, nrec - 1, iters, out);
+                else hipLaunchKernelGGL(k_shape<7>, dim3(blocks), dim3(64), 0, nullptr, pool, nrec - 1, iters, out);
                 hipEventRecord(e1, nullptr);
                 hipEventSynchronize(e1);
             }
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
             const double insts_per_cu = (double)waves_per_cu * iters * 8;  // wave-level load instructions per CU
-            const double bytes = (double)blocks * 64 * iters * (mode == 2 ? 64.0 : (mode >= 3 ? 32.0 : 128.0));
+            const double bytes = (double)blocks * 64 * iters * (mode == 2 ? 64.0 : ((mode >= 3 && mode <= 5) ? 32.0 : 128.0));
             printf("pool %8u records (%7.0f KB)  %s : %8.3f ms  %7.1f ns per wave-level load per CU  %8.1f GB/s aggregate\n", nrec, nrec * 128 / 1024.0,
-                   mode == 0 ? "lane per record, 16 B  " : (mode == 1 ? "8 lanes per record,16 B" : (mode == 2 ? "lane per record, 8 B   " : (mode == 3 ? "lane per record, 4 B   " : (mode == 4 ? "wave reads 256 B, 4 B  " : "8 lanes per record, 4 B")))), ms, ms * 1e6 / insts_per_cu, bytes / ms / 1e6);
+                   mode == 0 ? "lane per record, 16 B  " : (mode == 1 ? "8 lanes per record,16 B" : (mode == 2 ? "lane per record, 8 B   " : (mode == 3 ? "lane per record, 4 B   " : (mode == 4 ? "wave reads 256 B, 4 B  " : (mode == 5 ? "8 lanes per record, 4 B" : (mode == 6 ? "all lanes 1 record,16 B" : "1 record, scalar loads ")))))), ms, ms * 1e6 / insts_per_cu, bytes / ms / 1e6);
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
         hipFree(pool);
