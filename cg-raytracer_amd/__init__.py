@@ -106,11 +106,11 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/cgrt.h declares
 EXPORTS = [
-    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_scene_build_info", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
+    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_kernel_shape", "cgrt_get_kernel_shape", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_scene_build_info", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_record_sizes",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_debug_layout_hash", "cgrt_set_build_threads", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
-    "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version",
+    "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version", "cgrt_source_hash",
 ]  # fmt: skip
 
 
@@ -128,6 +128,7 @@ def lib() -> C.CDLL:
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.cgrt_last_error.restype = C.c_char_p
     L.cgrt_version.restype = C.c_char_p
+    L.cgrt_source_hash.restype = C.c_char_p
     L.cgrt_scene_create.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, i32, C.POINTER(vp)]
     L.cgrt_scene_destroy.argtypes = [vp]
     L.cgrt_scene_destroy.restype = None
@@ -136,8 +137,12 @@ def lib() -> C.CDLL:
     L.cgrt_set_leaf_accel.argtypes = [i32, i32]
     L.cgrt_num_subnodes.argtypes = [vp]
     L.cgrt_debug_check_layout.argtypes = [vp]
+    L.cgrt_debug_layout_hash.argtypes = [vp, C.POINTER(u64)]
+    L.cgrt_set_build_threads.argtypes = [i32]
     L.cgrt_set_primary_mode.argtypes = [i32]
     L.cgrt_set_fast_tree.argtypes = [i32]
+    L.cgrt_set_kernel_shape.argtypes = [i32, u64]
+    L.cgrt_get_kernel_shape.argtypes = [C.POINTER(i32), C.POINTER(u64)]
     L.cgrt_scene_set_walk.argtypes = [vp, i32]
     L.cgrt_scene_walk.argtypes = [vp]
     L.cgrt_scene_build_info.argtypes = [vp, vp]
@@ -227,9 +232,31 @@ def set_primary_mode(mode: int) -> None:
     _check(lib().cgrt_set_primary_mode(int(mode)))
 
 
+def set_kernel_shape(mode: int = -1, max_rays: int = 0) -> None:
+    """-1 = by launch size (launches of at most max_rays rays take the quad-per-ray shape), 0 = lane per ray, 1 = quad per ray;
+    max_rays = 0 keeps the threshold.  Same results either way."""
+    _check(lib().cgrt_set_kernel_shape(int(mode), int(max_rays)))
+
+
+def kernel_shape() -> Tuple[int, int]:
+    m, r = C.c_int(), C.c_uint64()
+    _check(lib().cgrt_get_kernel_shape(C.byref(m), C.byref(r)))
+    return int(m.value), int(r.value)
+
+
+def set_build_threads(threads: int = 0) -> None:
+    """Worker threads of the host builders for scenes created afterwards (0 = hardware concurrency); the arrays do not depend on it."""
+    _check(lib().cgrt_set_build_threads(int(threads)))
+
+
 def set_fast_tree(mode: int) -> None:
     """Process-wide build option: -1 = fast tree for scenes with fat leaves (default), 0 = never, 1 = whenever possible."""
     _check(lib().cgrt_set_fast_tree(int(mode)))
+
+
+def source_hash() -> str:
+    """sha256[:16] of the sources the loaded library was built from (include/cgrt.h cgrt_source_hash)."""
+    return lib().cgrt_source_hash().decode()
 
 
 def device_count() -> int:
@@ -362,6 +389,12 @@ class Scene:
     def check_layout(self) -> None:
         """cgrt_debug_check_layout: raises when a reference of the record arrays is inconsistent."""
         _check(lib().cgrt_debug_check_layout(self._h))
+
+    def layout_hash(self) -> int:
+        """cgrt_debug_layout_hash: FNV-1a over every array the device reads."""
+        h = C.c_uint64()
+        _check(lib().cgrt_debug_layout_hash(self._h, C.byref(h)))
+        return int(h.value)
 
     def render(self, cam, W: int, H: int, lights=None, max_level: int = 2):
         """cgrt_render: the whole shading/recursion driver on the device. Returns (rgb[W*H,3], stats dict)."""

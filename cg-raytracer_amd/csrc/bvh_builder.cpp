@@ -13,6 +13,7 @@
 #include "bvh_builder.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -290,10 +291,10 @@ static bool plane_is_tame(const float* a, const float* b, const float* c, const 
 
 // The leaves are independent: contiguous ranges of them are built on worker threads into private node arrays, which are
 // then concatenated in leaf order -- the result is the array a single thread would have produced, node for node.
-void build_leaf_accelerators(BuiltBvh& out, int leaf_tris) {
+void build_leaf_accelerators(BuiltBvh& out, int leaf_tris, int threads) {
     const int lt = leaf_tris < 1 ? 1 : leaf_tris;
     const size_t nleaves = out.leaves.size();
-    unsigned nthreads = std::thread::hardware_concurrency();
+    unsigned nthreads = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
     if (nthreads > 16) nthreads = 16;
     if (nthreads < 1 || nleaves < 64) nthreads = 1;
     std::vector<std::vector<SubNode>> part(nthreads);
@@ -338,12 +339,29 @@ void build_leaf_accelerators(BuiltBvh& out, int leaf_tris) {
 //     final t -- and accepts the same triangle; anything else (a failed box, an equal-t tie, an origin-on-plane
 //     acceptance) sends the ray through the exact walk.
 // Nothing here changes what the exact walk reads.
+// Threads.  The recursion is a pre-order walk (a node, then its four subtrees one after the other), each subtree a pure function
+// of its own range of idx.  The top TOP_PAR_LEVELS levels are built by the caller's thread into a vector of their own; every
+// subtree below them that holds more than TOP_TASK_MIN items becomes a task built by a worker thread into a vector of ITS own,
+// and stitch() then emits top nodes and task vectors in the sequential build's pre-order: the arrays are identical to the
+// single-threaded build's, node for node (tests/test_builder.py compares them).  While a part is being built a reference to one
+// of its own new nodes carries TOP_LOCAL (index into the part), a reference to a task TOP_TASK (task number); item references
+// (accelerator roots, runs) are absolute and carry neither.
+static const uint32_t TOP_LOCAL = 0x20000000u, TOP_TASK = 0x10000000u;  // free bits of a node reference (indices use 26)
+static const int TOP_PAR_LEVELS = 2;
+static const uint32_t TOP_TASK_MIN = 4096;
+struct TopTask {
+    uint32_t b, e;
+    int depth_left;
+    std::vector<SubNode> nodes;
+    uint32_t root = REF_NONE;
+};
 struct TopBuilder {
     const std::vector<Box6>& box;     // item boxes
     const std::vector<uint32_t>& ref; // item references (accelerator roots or runs, builder-local indices)
-    std::vector<SubNode>& nodes;
-    std::vector<uint32_t> idx;
-    std::vector<float> cen[3];
+    std::vector<SubNode>& nodes;      // this part's new nodes
+    std::vector<uint32_t>& idx;       // shared; a part only touches its own range
+    const std::vector<float>* cen;    // [3], shared, read-only
+    std::vector<TopTask>* tasks;      // where the top part leaves its tasks (nullptr: build everything here)
     std::vector<float> rarea;
 
     static Box6 empty_box() {
@@ -487,8 +505,15 @@ struct TopBuilder {
         if (best_axis >= 0) std::copy(ord[best_axis].begin(), ord[best_axis].end(), idx.begin() + b);
         return b + best_k;
     }
-    uint32_t child_ref(uint32_t b, uint32_t e, int depth_left) { return (e - b == 1) ? ref[idx[b]] : build4(b, e, depth_left); }
-    uint32_t build4(uint32_t b, uint32_t e, int depth_left) {  // more than one item
+    uint32_t child_ref(uint32_t b, uint32_t e, int depth_left, int par_levels) {
+        if (e - b == 1) return ref[idx[b]];
+        if (tasks && par_levels <= 0 && e - b > TOP_TASK_MIN) {  // a subtree for a worker thread
+            tasks->push_back(TopTask{b, e, depth_left, {}, REF_NONE});
+            return TOP_TASK | (uint32_t)(tasks->size() - 1);
+        }
+        return build4(b, e, depth_left, par_levels);
+    }
+    uint32_t build4(uint32_t b, uint32_t e, int depth_left, int par_levels = 0) {  // more than one item; returns TOP_LOCAL | index in `nodes`
         const uint32_t me = (uint32_t)nodes.size();
         nodes.push_back(SubNode());
         nodes.push_back(SubNode());
@@ -511,7 +536,7 @@ struct TopBuilder {
         for (int c = 0; c < 4; c++) {
             if (c < nc) {
                 cbox[c] = range_box(cb[c], ce[c]);
-                cref[c] = child_ref(cb[c], ce[c], depth_left - 1);
+                cref[c] = child_ref(cb[c], ce[c], depth_left - 1, par_levels - 1);
             } else {
                 cbox[c] = empty_box();
                 cref[c] = REF_NONE;
@@ -525,13 +550,42 @@ struct TopBuilder {
             N.ref1 = cref[2 * r + 1];
             N.pad[0] = N.pad[1] = 0;
         }
-        return me;
+        return TOP_LOCAL | me;
     }
 };
 
+// Appends the part `src` (references TOP_LOCAL = own nodes, TOP_TASK = a task's part, anything else absolute) to `dst` in the
+// sequential build's pre-order, starting at its node `r`; returns the absolute index of that node.
+static uint32_t stitch(std::vector<SubNode>& dst, const std::vector<SubNode>& src, uint32_t r, const std::vector<TopTask>& tasks) {
+    const uint32_t at = (uint32_t)dst.size();
+    dst.push_back(src[r]);
+    dst.push_back(src[r + 1]);
+    for (int h = 0; h < 2; h++)
+        for (int c = 0; c < 2; c++) {
+            const uint32_t cr = c ? src[r + h].ref1 : src[r + h].ref0;
+            uint32_t out_ref = cr;
+            if (cr != REF_NONE && !(cr & REF_LEAF)) {
+                if (cr & TOP_LOCAL) {
+                    out_ref = stitch(dst, src, cr & ~TOP_LOCAL, tasks);
+                } else if (cr & TOP_TASK) {  // a task's part is already in pre-order: append it whole, shifted
+                    const TopTask& T = tasks[cr & ~TOP_TASK];
+                    const uint32_t base = (uint32_t)dst.size();
+                    for (SubNode N : T.nodes) {
+                        for (uint32_t* q : {&N.ref0, &N.ref1})
+                            if (*q != REF_NONE && !(*q & REF_LEAF) && (*q & TOP_LOCAL)) *q = (*q & ~TOP_LOCAL) + base;
+                        dst.push_back(N);
+                    }
+                    out_ref = (T.root & ~TOP_LOCAL) + base;
+                }
+            }
+            (c ? dst[at + h].ref1 : dst[at + h].ref0) = out_ref;
+        }
+    return at;
+}
+
 // Called before the references are made global: everything is still in builder-local indices (subnode index, record
 // index), which the globalisation loop of build_reference_bvh then shifts like every other accelerator reference.
-void build_fast_tree(BuiltBvh& out, bool force, bool leaf_accel, int open) {
+void build_fast_tree(BuiltBvh& out, bool force, bool leaf_accel, int open, int threads) {
     if (open < 0) open = 0;
     if (open > SUB_MAX_DEPTH) open = SUB_MAX_DEPTH;
     out.fast_root = REF_NONE;
@@ -619,14 +673,42 @@ void build_fast_tree(BuiltBvh& out, bool force, bool leaf_accel, int open) {
         out.fast_root = ref[0];
         return;
     }
-    TopBuilder tb{box, ref, out.subnodes, {}, {}, {}};
-    tb.idx.resize(nitems);
-    for (int a = 0; a < 3; a++) tb.cen[a].resize(nitems);
+    std::vector<uint32_t> idx(nitems);
+    std::vector<float> cen[3];
+    for (int a = 0; a < 3; a++) cen[a].resize(nitems);
     for (uint32_t i = 0; i < nitems; i++) {
-        tb.idx[i] = i;
-        for (int a = 0; a < 3; a++) tb.cen[a][i] = 0.5f * box[i].lo[a] + 0.5f * box[i].hi[a];
+        idx[i] = i;
+        for (int a = 0; a < 3; a++) cen[a][i] = 0.5f * box[i].lo[a] + 0.5f * box[i].hi[a];
     }
-    out.fast_root = tb.build4(0, nitems, TOP_MAX_DEPTH + open);
+    unsigned nthreads = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads < 1 || nitems <= 4 * TOP_TASK_MIN) nthreads = 1;
+    // the top levels on this thread (their subtrees become tasks), the tasks on workers, then everything in pre-order
+    std::vector<SubNode> top;
+    std::vector<TopTask> tasks;
+    TopBuilder tb{box, ref, top, idx, cen, nthreads > 1 ? &tasks : nullptr, {}};
+    const uint32_t root = tb.build4(0, nitems, TOP_MAX_DEPTH + open, TOP_PAR_LEVELS);
+    if (!tasks.empty()) {
+        std::vector<uint32_t> by_size(tasks.size());
+        for (uint32_t i = 0; i < by_size.size(); i++) by_size[i] = i;
+        std::sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) { return tasks[x].e - tasks[x].b > tasks[y].e - tasks[y].b; });
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const uint32_t k = next.fetch_add(1);
+                if (k >= by_size.size()) return;
+                TopTask& T = tasks[by_size[k]];
+                TopBuilder w{box, ref, T.nodes, idx, cen, nullptr, {}};
+                T.root = w.build4(T.b, T.e, T.depth_left);
+            }
+        };
+        std::vector<std::thread> pool;
+        const unsigned nt = (unsigned)std::min<size_t>(nthreads, tasks.size());
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+    }
+    out.fast_root = stitch(out.subnodes, top, root & ~TOP_LOCAL, tasks);
 }
 
 }  // namespace
@@ -741,7 +823,7 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
         R.left = TopoNode{ll, nd.level + 1, B.bounds(nd.first, lcount), {-1, -1}, nd.first, lcount};
         R.right = TopoNode{rl, nd.level + 1, B.bounds(nd.first + lcount, nd.count - lcount), {-1, -1}, nd.first + lcount, nd.count - lcount};
     };
-    unsigned nthreads = std::thread::hardware_concurrency();
+    unsigned nthreads = opt.threads > 0 ? (unsigned)opt.threads : std::thread::hardware_concurrency();
     if (nthreads > 16) nthreads = 16;
     if (nthreads < 1) nthreads = 1;
     for (size_t lb = 0, le = out.nodes.size(); lb < le; lb = le, le = out.nodes.size()) {  // [lb, le) = the nodes of one level
@@ -794,44 +876,73 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
     auto ref_of = [&](int node) -> uint32_t {
         return out.nodes[node].leaf ? (REF_LEAF | (uint32_t)out.node_to_ref_index[node]) : (uint32_t)out.node_to_ref_index[node];
     };
-    uint32_t w = 0;
-    for (size_t i = 0; i < out.nodes.size(); i++) {
-        const TopoNode& n = out.nodes[i];
-        if (n.leaf) {
+    // leaf records on worker threads: every leaf owns a disjoint range of the record arrays, whose start is the prefix sum of the
+    // counts in node order (the sequential numbering); inner nodes are few and stay on this thread
+    std::vector<size_t> leaf_nodes;
+    {
+        uint32_t w = 0;
+        for (size_t i = 0; i < out.nodes.size(); i++) {
+            const TopoNode& n = out.nodes[i];
+            if (!n.leaf) continue;
             LeafRec& L = out.leaves[out.node_to_ref_index[i]];
             L.first = w;
             L.count = n.count;
             L.sub_root = REF_NONE;
             L.path_len = 0;
-            for (uint32_t k = 0; k < n.count; k++, w++) {
-                const uint32_t p = out.order[n.first + k];
-                const float* a = B.vpos(sc.tri[3 * (size_t)p]);
-                const float* b = B.vpos(sc.tri[3 * (size_t)p + 1]);
-                const float* c = B.vpos(sc.tri[3 * (size_t)p + 2]);
-                TriRecord& T = out.tris[w];
-                std::memcpy(T.v0, a, 12);
-                std::memcpy(T.v1, b, 12);
-                std::memcpy(T.v2, c, 12);
-                F3 pn;
-                float D;
-                triangle_plane(f3(a[0], a[1], a[2]), f3(b[0], b[1], b[2]), f3(c[0], c[1], c[2]), pn, D);
-                T.n[0] = pn.x;
-                T.n[1] = pn.y;
-                T.n[2] = pn.z;
-                T.D = D;
-                T.prim_id = p;
-                T.mesh_id = sc.tri_mesh[p];
-                T.scan_k = k;
-                if (!plane_is_tame(a, b, c, pn)) {
-                    out.leaf_wild[out.node_to_ref_index[i]] = 1;
-                    out.has_wild = true;
-                }
-                TriNormals& N = out.tri_normals[w];
-                std::memcpy(N.n1, a + 3, 12);
-                std::memcpy(N.n2, b + 3, 12);
-                std::memcpy(N.n3, c + 3, 12);
-            }
+            w += n.count;
+            leaf_nodes.push_back(i);
+        }
+    }
+    auto fill_leaf = [&](size_t i) -> bool {
+        const TopoNode& n = out.nodes[i];
+        const LeafRec& L = out.leaves[out.node_to_ref_index[i]];
+        bool wild = false;
+        uint32_t w = L.first;
+        for (uint32_t k = 0; k < n.count; k++, w++) {
+            const uint32_t p = out.order[n.first + k];
+            const float* a = B.vpos(sc.tri[3 * (size_t)p]);
+            const float* b = B.vpos(sc.tri[3 * (size_t)p + 1]);
+            const float* c = B.vpos(sc.tri[3 * (size_t)p + 2]);
+            TriRecord& T = out.tris[w];
+            std::memcpy(T.v0, a, 12);
+            std::memcpy(T.v1, b, 12);
+            std::memcpy(T.v2, c, 12);
+            F3 pn;
+            float D;
+            triangle_plane(f3(a[0], a[1], a[2]), f3(b[0], b[1], b[2]), f3(c[0], c[1], c[2]), pn, D);
+            T.n[0] = pn.x;
+            T.n[1] = pn.y;
+            T.n[2] = pn.z;
+            T.D = D;
+            T.prim_id = p;
+            T.mesh_id = sc.tri_mesh[p];
+            T.scan_k = k;
+            if (!plane_is_tame(a, b, c, pn)) wild = true;
+            TriNormals& N = out.tri_normals[w];
+            std::memcpy(N.n1, a + 3, 12);
+            std::memcpy(N.n2, b + 3, 12);
+            std::memcpy(N.n3, c + 3, 12);
+        }
+        return wild;
+    };
+    {
+        const unsigned nt = (sc.ntris < 65536 || leaf_nodes.size() < 2) ? 1u : (unsigned)std::min<size_t>(opt.threads > 0 ? (unsigned)opt.threads : nthreads, leaf_nodes.size());
+        auto work = [&](unsigned t) {
+            for (size_t k = t; k < leaf_nodes.size(); k += nt)
+                if (fill_leaf(leaf_nodes[k])) out.leaf_wild[out.node_to_ref_index[leaf_nodes[k]]] = 1;  // (one byte per leaf, one writer per leaf)
+        };
+        if (nt <= 1) {
+            work(0);
         } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; t++) pool.emplace_back(work, t);
+            for (std::thread& th : pool) th.join();
+        }
+        for (uint8_t wl : out.leaf_wild) out.has_wild = out.has_wild || wl;
+    }
+    for (size_t i = 0; i < out.nodes.size(); i++) {
+        const TopoNode& n = out.nodes[i];
+        if (!n.leaf) {
             NodePacket& P = out.packets[out.node_to_ref_index[i]];
             const TopoNode &l = out.nodes[n.child[0]], &r = out.nodes[n.child[1]];
             std::memcpy(P.lbox, &l.box, 24);
@@ -848,9 +959,9 @@ bool build_reference_bvh(const HostScene& sc, const BuildOptions& opt, BuiltBvh&
             if (!(c <= std::numeric_limits<float>::max())) out.geometry_finite = false;
         }
     const auto t_a = std::chrono::steady_clock::now();
-    if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris);
+    if (opt.leaf_accel) build_leaf_accelerators(out, opt.sub_leaf_tris, opt.threads);
     const auto t_b = std::chrono::steady_clock::now();
-    if (opt.fast_tree != 0) build_fast_tree(out, opt.fast_tree > 0, opt.leaf_accel, opt.fast_open);
+    if (opt.fast_tree != 0) build_fast_tree(out, opt.fast_tree > 0, opt.leaf_accel, opt.fast_open, opt.threads);
     if (getenv("CGRT_BUILD_TIMES"))
         fprintf(stderr, "build: reference tree + records %.3f s, leaf accelerators %.3f s, fast tree %.3f s\n",
                 std::chrono::duration<double>(t_a - t_start).count(), std::chrono::duration<double>(t_b - t_a).count(),

@@ -61,6 +61,7 @@ struct BuildOptions {
     bool leaf_accel = true;  // build the in-leaf accelerator (results are identical either way)
     int sub_leaf_tris = SUB_LEAF_TRIS;
     int fast_open = SUB_MAX_DEPTH;  // levels of the leaves' accelerators handed to the top tree's SAH as separate items (build_fast_tree): all of them = a global tree over the runs
+    int threads = 0;     // worker threads of the builders (0 = hardware concurrency, at most 16); the arrays do not depend on it
     int fast_tree = -1;  // certified walk's structures: -1 = whenever possible, except without in-leaf accelerators or below 16 triangles; 0 = never; 1 = whenever possible
 };
 

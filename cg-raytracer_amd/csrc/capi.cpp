@@ -378,6 +378,19 @@ int cgrt_set_primary_mode(int mode) {
     g_primary_mode.store(mode);
     return CGRT_OK;
 }
+int cgrt_set_kernel_shape(int mode, uint64_t max_rays) {
+    if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (by launch size), 0 (lane per ray) or 1 (quad per ray)");
+    set_quad_shape(mode, max_rays);
+    return CGRT_OK;
+}
+int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays) {
+    int m = 0;
+    unsigned long long r = 0;
+    get_quad_shape(&m, &r);
+    if (mode) *mode = m;
+    if (max_rays) *max_rays = r;
+    return CGRT_OK;
+}
 int cgrt_set_fast_tree(int mode) {
     if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (default policy), 0 (never) or 1 (whenever possible)");
     std::lock_guard<std::mutex> lk(g_options_mutex);
@@ -432,6 +445,33 @@ int64_t cgrt_leaf_prims(const CgrtScene* s, int node, uint32_t* out, uint32_t ca
 // Walks the host copy of the device records and checks every reference: child references of the reference tree, leaf
 // references in both encodings (REF_LEAF_ACCEL), accelerator child references and runs, alignment of 4-wide nodes, and
 // that every triangle is reachable exactly once through the accelerator of its leaf.  0 = consistent.
+int cgrt_set_build_threads(int threads) {
+    if (threads < 0 || threads > 256) return fail(CGRT_E_ARG, "threads must be in 0..256 (0 = hardware concurrency)");
+    std::lock_guard<std::mutex> lk(g_options_mutex);
+    g_build_options.threads = threads;
+    return CGRT_OK;
+}
+int cgrt_debug_layout_hash(const CgrtScene* s, uint64_t* out) {
+    if (!s || !out) return fail(CGRT_E_ARG, "NULL argument");
+    const BuiltBvh& B = s->bvh;
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over every array the device reads, in a fixed order
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* q = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; i++) h = (h ^ q[i]) * 1099511628211ull;
+        h = (h ^ (uint64_t)n) * 1099511628211ull;
+    };
+    mix(B.packets.data(), B.packets.size() * sizeof(NodePacket));
+    mix(B.subnodes.data(), B.subnodes.size() * sizeof(SubNode));
+    mix(B.tris.data(), B.tris.size() * sizeof(TriRecord));
+    mix(B.leaves.data(), B.leaves.size() * sizeof(LeafRec));
+    mix(B.tri_normals.data(), B.tri_normals.size() * sizeof(TriNormals));
+    mix(B.paths.data(), B.paths.size() * sizeof(float));
+    mix(B.tri_leaf.data(), B.tri_leaf.size() * sizeof(uint32_t));
+    mix(&B.fast_root, sizeof(B.fast_root));
+    mix(&B.root_ref, sizeof(B.root_ref));
+    *out = h;
+    return CGRT_OK;
+}
 int cgrt_debug_check_layout(CgrtScene* s) {
     if (!s) return fail(CGRT_E_ARG, "NULL scene");
     const BuiltBvh& B = s->bvh;

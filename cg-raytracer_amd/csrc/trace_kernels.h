@@ -26,6 +26,11 @@ struct SoftDev {
 
 // threads per workgroup the ray-list kernels (batch, soft shadow) are launched with for this scene; frames carry theirs in FrameDev::block
 int trace_block(const SceneDev& S);
+// kernel shape per launch (walk_quad.h): mode -1 = by size (launches of at most max_rays rays take the quad shape), 0 = never, 1 = always;
+// max_rays 0 keeps the current threshold.  Results do not depend on the shape.
+void set_quad_shape(int mode, unsigned long long max_rays);
+void get_quad_shape(int* mode, unsigned long long* max_rays);
+bool quad_shape_for(const SceneDev& S, unsigned long long rays);
 // counters (optional): 5 x u64 device words {rays, inner_visits, leaf_visits, tri_tests, sub_visits}, accumulated.
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
                                 unsigned long long* counters, hipStream_t stream);

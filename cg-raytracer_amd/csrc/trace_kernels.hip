@@ -8,45 +8,74 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
-#include "walk_fast.h"
+#include "walk_quad.h"
+
+#ifndef CGRT_QUAD_MAX_RAYS_DEFAULT
+#define CGRT_QUAD_MAX_RAYS_DEFAULT 262144ull  // launches of at most this many rays take the quad shape (walk_quad.h); from measurements
+#endif
 
 namespace cgrt {
 
-template <bool COUNT, bool FAST>
+// Quad shape (walk_quad.h): a launch of single-wave workgroups, FOUR per 8x8 tile.  Workgroup b serves tile-block
+// tb = (b / 32) * 8 + b % 8 -- the workgroup index the lane-per-ray launch with 64 threads gives that tile, same blockIdx % 8
+// residue, i.e. same XCD -- and of its 64 pixels the 16 with index (b / 8 % 4) * 16 + threadIdx / 4; the four lanes of a quad
+// carry the same pixel.  Results land where the lane-per-ray launch puts them (packed or not).
+template <bool QUAD>
+__device__ __forceinline__ bool frame_pixel(const FrameDev& F, int& x, int& y, size_t& packed_index, bool& writer) {
+    if (QUAD) {
+        const uint32_t b = blockIdx.x, tb = ((b >> 5) << 3) | (b & 7u);
+        const uint32_t p = ((b >> 3) & 3u) * 16u + (threadIdx.x >> 2);
+        packed_index = (size_t)tb * 64u + p;
+        writer = (threadIdx.x & 3u) == 0u;
+        return tile_pixel_of(F, tb, p, x, y);
+    }
+    packed_index = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    writer = true;
+    return tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y);
+}
+
+template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                         unsigned long long* counters) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
-    const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
-    const bool active = tile_pixel(F, lane, x, y);
+    size_t pidx;
+    bool writer;
+    const bool active = frame_pixel<QUAD>(F, x, y, pidx, writer);
     LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
     float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
     uint32_t hit_rec = REF_NONE;
-    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
-    if (active) {
-        const size_t pix = F.packed ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)y * F.W + x;
+    if (QUAD)
+        walk_tree_quad<COUNT>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), cnt);
+    else
+        walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
+    if (active && writer) {
+        const size_t pix = F.packed ? pidx : (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
-    if (COUNT) flush_counters(cnt, active, counters);
+    if (COUNT) flush_counters(cnt, active && writer, counters);
 }
 
 // Primary frame for the shading wavefront (cgrt_render): the fused kernel's walk, but only the rays that HIT are written,
 // appended to a compact list {ray, hit, normal, pixel} (one atomic per workgroup, lanes ranked by ballot; workgroups
 // finish roughly in launch order, so the list keeps the frame's tile order).  Pixels that miss need no further work upstream
 // either (main.cpp:293: black).  count = one zeroed device word.
-template <bool COUNT, bool FAST>
+template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
                                                 float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count,
                                                 unsigned long long* counters, float* __restrict__ rgb) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
-    const bool active = tile_pixel(F, lane, x, y);
-    if (active && rgb) {  // every pixel this rank owns starts black (main.cpp:293); the hits are written over it at the end of the frame
+    size_t pidx;
+    bool writer;
+    const bool active = frame_pixel<QUAD>(F, x, y, pidx, writer);
+    if (active && writer && rgb) {  // every pixel this rank owns starts black (main.cpp:293); the hits are written over it at the end of the frame
         float* p = rgb + 3ull * ((unsigned long long)y * F.W + x);
         p[0] = p[1] = p[2] = 0.0f;
     }
@@ -57,12 +86,15 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
     float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
     uint32_t hit_rec = REF_NONE;
-    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
-    if (active) resolve_hit(S, o, d, t, hit_rec, true, h, nn);
-    if (COUNT) flush_counters(cnt, active, counters);
+    if (QUAD)
+        walk_tree_quad<COUNT>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), cnt);
+    else
+        walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
+    if (active && writer) resolve_hit(S, o, d, t, hit_rec, true, h, nn);
+    if (COUNT) flush_counters(cnt, active && writer, counters);
     // one atomic per workgroup (same-address atomics serialise at the L2); the workgroup's LDS is only released when its
     // last wave ends anyway, so waiting for it here costs no occupancy
-    const bool keep = active && h.hit != 0;
+    const bool keep = active && writer && h.hit != 0;
     const unsigned long long m = __ballot(keep);
     uint32_t* s_cnt = CGRT_BLOCK_SCRATCH(s_lds);
     const unsigned w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -104,7 +136,7 @@ __global__ __launch_bounds__(CGRT_BLOCK) void k_clear_owned(FrameDev F, float* _
 }
 
 // dcount (optional): device word holding the number of rays actually present (<= n); the grid covers n.
-template <bool COUNT, bool FAST>
+template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                                             unsigned long long* counters, const uint32_t* __restrict__ dcount) {
@@ -113,7 +145,9 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
         const unsigned long long present = *dcount;
         n = present < n ? present : n;
     }
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long i = QUAD ? (g >> 2) : g;  // quad shape: the four lanes of a quad carry the same ray
+    const bool writer = !QUAD || (threadIdx.x & 3u) == 0u;
     const bool active = i < n;
     LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
@@ -125,16 +159,19 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
         t = r[6];
     }
     uint32_t hit_rec = REF_NONE;
-    walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
-    if (active) finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
-    if (COUNT) flush_counters(cnt, active, counters);
+    if (QUAD)
+        walk_tree_quad<COUNT>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), cnt);
+    else
+        walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
+    if (active && writer) finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
+    if (COUNT) flush_counters(cnt, active && writer, counters);
 }
 
 // pointInShadow's rays (main.cpp:104-135) for the shading wavefront: dist[i] = |fromPosToLight| of ray i.  The caller only
 // evaluates `hit && !(t + epsilon >= dist)`: the certified walk answers that question directly (WALK_OCCLUDED: bounded by
 // the light's distance, stops at the first qualifying triangle); a ray without certificate gets the exact closest hit.
 // hits[i] therefore holds a hit that decides the test like the reference's own, not necessarily the closest one.
-template <bool COUNT, bool FAST>
+template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ rays, const float* __restrict__ dist, unsigned long long n,
                                        CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount, unsigned long long* counters) {
     extern __shared__ uint32_t s_lds[];
@@ -142,7 +179,9 @@ __global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ ray
         const unsigned long long present = *dcount;
         n = present < n ? present : n;
     }
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long i = QUAD ? (g >> 2) : g;
+    const bool writer = !QUAD || (threadIdx.x & 3u) == 0u;
     const bool active = i < n;
     LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
@@ -155,9 +194,12 @@ __global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ ray
         qlen = dist[i];
     }
     uint32_t hit_rec = REF_NONE;
-    walk_tree<COUNT, FAST, WALK_OCCLUDED>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt, qlen);
-    if (active) finish_ray(S, o, d, t, hit_rec, hits + i, nullptr);
-    if (COUNT) flush_counters(cnt, active, counters);
+    if (QUAD)
+        walk_tree_quad<COUNT, WALK_OCCLUDED>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), cnt, qlen);
+    else
+        walk_tree<COUNT, FAST, WALK_OCCLUDED>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt, qlen);
+    if (active && writer) finish_ray(S, o, d, t, hit_rec, hits + i, nullptr);
+    if (COUNT) flush_counters(cnt, active && writer, counters);
 }
 
 // Soft shadows of spherical lights (main.cpp:168-218): `samples` shadow rays per (hit item, light), generated in
@@ -255,11 +297,51 @@ int trace_block(const SceneDev& S) {
         else                                                                                                                  \
             hipLaunchKernelGGL((KERNEL<A, false>), dim3(grid), dim3(block), lds_bytes(block), stream, __VA_ARGS__);          \
     } while (0)
+// the quad shape (walk_quad.h): single-wave workgroups, four lanes per ray
+#define CGRT_LAUNCHQ(KERNEL, A, grid, stream, ...) \
+    hipLaunchKernelGGL((KERNEL<A, true, true>), dim3(grid), dim3(64), lds_bytes(64), stream, __VA_ARGS__)
+
+// ---- kernel shape per launch ----
+// Lane per ray (walk_fast.h) is the throughput shape; quad per ray (walk_quad.h) the latency shape: it spends four lanes on a
+// ray's set-up and certificate but walks a hard ray's chain ~1.5x faster and puts 16 rays in a wave instead of 64.  A launch
+// takes the quad shape when it is small enough that its time is the time of its hardest rays rather than the chip's throughput:
+// at most g_quad_max_rays rays (measured crossover, profiles/r3_exp_quad_shape.txt).  Results do not depend on the shape.
+static std::atomic<int> g_quad_mode{-1};                          // -1 = by size, 0 = never, 1 = whenever the scene has a fast tree
+static std::atomic<unsigned long long> g_quad_max_rays{CGRT_QUAD_MAX_RAYS_DEFAULT};
+void set_quad_shape(int mode, unsigned long long max_rays) {
+    g_quad_mode.store(mode < 0 ? -1 : (mode ? 1 : 0));
+    if (max_rays) g_quad_max_rays.store(max_rays);
+}
+void get_quad_shape(int* mode, unsigned long long* max_rays) {
+    *mode = g_quad_mode.load();
+    *max_rays = g_quad_max_rays.load();
+}
+bool quad_shape_for(const SceneDev& S, unsigned long long rays) {
+    static const int env_mode = [] {
+        const char* e = getenv("CGRT_QUAD_MODE");  // experiment knob: -1 / 0 / 1
+        return e ? atoi(e) : -2;
+    }();
+    static const unsigned long long env_max = [] {
+        const char* e = getenv("CGRT_QUAD_MAX_RAYS");
+        return e ? strtoull(e, nullptr, 10) : 0ull;
+    }();
+    if (S.fast_root == REF_NONE || trace_block(S) != 64) return false;
+    const int mode = env_mode != -2 ? env_mode : g_quad_mode.load();
+    if (mode >= 0) return mode != 0;
+    return rays <= (env_max ? env_max : g_quad_max_rays.load());
+}
 
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
                                 unsigned long long* counters, hipStream_t stream) {
     if (F.nblocks == 0) return hipSuccess;
     const bool fast = S.fast_root != REF_NONE;
+    if (F.block == 64 && quad_shape_for(S, (unsigned long long)F.nblocks * 64ull)) {
+        if (counters)
+            CGRT_LAUNCHQ(k_trace_primary, true, 4u * F.nblocks, stream, S, C, F, hits, normals, counters);
+        else
+            CGRT_LAUNCHQ(k_trace_primary, false, 4u * F.nblocks, stream, S, C, F, hits, normals, counters);
+        return hipGetLastError();
+    }
     if (counters)
         CGRT_LAUNCH2(k_trace_primary, true, fast, F.nblocks, (unsigned)F.block, stream, S, C, F, hits, normals, counters);
     else
@@ -272,6 +354,13 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
     const unsigned block = (unsigned)trace_block(S);
     const unsigned blocks = grid_for(n, block);
     const bool fast = S.fast_root != REF_NONE;
+    if (quad_shape_for(S, n)) {
+        if (counters)
+            CGRT_LAUNCHQ(k_trace_batch, true, grid_for(4ull * n, 64), stream, S, rays, n, hits, normals, counters, dcount);
+        else
+            CGRT_LAUNCHQ(k_trace_batch, false, grid_for(4ull * n, 64), stream, S, rays, n, hits, normals, counters, dcount);
+        return hipGetLastError();
+    }
     if (counters)
         CGRT_LAUNCH2(k_trace_batch, true, fast, blocks, block, stream, S, rays, n, hits, normals, counters, dcount);
     else
@@ -284,6 +373,13 @@ hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float
     const unsigned block = (unsigned)trace_block(S);
     const unsigned blocks = grid_for(n, block);
     const bool fast = S.fast_root != REF_NONE;
+    if (quad_shape_for(S, n)) {
+        if (counters)
+            CGRT_LAUNCHQ(k_trace_shadow, true, grid_for(4ull * n, 64), stream, S, rays, dist, n, hits, dcount, counters);
+        else
+            CGRT_LAUNCHQ(k_trace_shadow, false, grid_for(4ull * n, 64), stream, S, rays, dist, n, hits, dcount, counters);
+        return hipGetLastError();
+    }
     if (counters)
         CGRT_LAUNCH2(k_trace_shadow, true, fast, blocks, block, stream, S, rays, dist, n, hits, dcount, counters);
     else
@@ -295,6 +391,13 @@ hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, c
     if (F.nblocks == 0) return hipSuccess;
     const unsigned block = (unsigned)F.block;
     const bool fast = S.fast_root != REF_NONE;
+    if (F.block == 64 && quad_shape_for(S, (unsigned long long)F.nblocks * 64ull)) {
+        if (counters)
+            CGRT_LAUNCHQ(k_trace_primary_compact, true, 4u * F.nblocks, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
+        else
+            CGRT_LAUNCHQ(k_trace_primary_compact, false, 4u * F.nblocks, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
+        return hipGetLastError();
+    }
     if (counters)
         CGRT_LAUNCH2(k_trace_primary_compact, true, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
     else

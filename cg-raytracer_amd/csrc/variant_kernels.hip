@@ -188,9 +188,10 @@ __global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
                         pix = (size_t)y * F.W + x;
                         primary_ray(C, F.W, F.H, x, y, W.o, W.d);
                         W.t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
-                        if (walk_begin(S, W))
+                        if (walk_begin(S, W)) {
                             active = true;
-                        else
+                            if (COUNT) cnt.entered++;
+                        } else
                             finish_ray(S, W.o, W.d, W.t, W.hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
                     }
                 }
@@ -212,8 +213,9 @@ __global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         }
     }
     if (COUNT) {
-        unsigned long long v[5] = {nrays, cnt.inner, cnt.leaf, cnt.tri, cnt.sub};
-        for (int k = 0; k < 5; k++) {
+        // all eight counters of CgrtCounters (this kernel walks exactly: no certificates, no fallbacks)
+        unsigned long long v[8] = {nrays, cnt.inner, cnt.leaf, cnt.tri, cnt.sub, 0ull, 0ull, cnt.entered};
+        for (int k = 0; k < 8; k++) {
             unsigned long long x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if (lane == 0 && x) atomicAdd(counters + k, x);

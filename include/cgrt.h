@@ -110,6 +110,13 @@ int cgrt_num_subnodes(const CgrtScene* scene);
 /* Scheduling of the fused primary-frame kernel (results are identical; tested): 0 = one wave per 8x8 tile,
  * 1 = persistent waves that pull tiles from per-XCD queues and refill finished lanes.  Process-wide. */
 int cgrt_set_primary_mode(int mode);
+/* Kernel shape of the certified walk, chosen per launch (no counterpart upstream; DESIGN.md "Latency shape"; results are
+ * identical, tested): lane per ray is the throughput shape; quad per ray (four lanes test a node's four boxes, 16 rays per wave)
+ * shortens the dependent chain of the hardest rays and is taken by launches of at most `max_rays` rays -- ray lists, and frames
+ * or frame shares (cgrt_trace_primary* with nranks > 1) -- when mode = -1 (default); 0 = lane per ray always, 1 = quad per ray
+ * whenever the scene has a fast tree.  max_rays = 0 keeps the current threshold.  Process-wide. */
+int cgrt_set_kernel_shape(int mode, uint64_t max_rays);
+int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays);
 /* Certified walk (no counterpart upstream; DESIGN.md "Certified walk").  The exact walk takes every step of the
  * reference's ordered descent (bvh.cpp:572-758) because its culling quirks are part of the result.  A scene may also
  * carry a "fast tree" (a 4-wide tree over the reference LEAVES) and per-leaf box paths: a ray then searches the fast
@@ -258,6 +265,12 @@ int cgrt_debug_fastdiv_check(int device, const float* a, const float* d, uint64_
 /* Diagnostic: validates every reference of the scene's record arrays on the host (tree child references, leaf references
  * in both encodings, accelerator nodes and runs, each triangle reachable exactly once).  Works on host-only scenes. */
 int cgrt_debug_check_layout(CgrtScene* scene);
+/* Diagnostic: FNV-1a hash over every array the device reads (node packets, accelerator + fast-tree nodes, triangle records, leaf
+ * table, vertex normals, certificate paths, leaf of every record, roots): two builds of the same scene must agree, whatever the
+ * number of builder threads (cgrt_set_build_threads: 0 = hardware concurrency, at most 16 are used; process-wide, for scenes
+ * created afterwards).  Works on host-only scenes. */
+int cgrt_debug_layout_hash(const CgrtScene* scene, uint64_t* out);
+int cgrt_set_build_threads(int threads);
 /* Bytes of one inner-node record / one triangle record / one in-leaf accelerator node / one result. */
 void cgrt_record_sizes(uint32_t* node_bytes, uint32_t* tri_bytes, uint32_t* sub_bytes, uint32_t* hit_bytes);
 
@@ -284,6 +297,9 @@ int cgrt_point_in_triangle_batch(int device, const float* in, uint64_t n, uint8_
 int cgrt_device_count(void);
 const char* cgrt_last_error(void);
 const char* cgrt_version(void);
+/* First 16 hex digits of the sha256 over the library's sources (every .hip, .cpp and .h file of csrc + this header, in name order) at build time:
+ * ties a committed profile to the kernels it was measured on (bench.py nulls roofline.traffic / roofline.measured when it differs). */
+const char* cgrt_source_hash(void);
 
 #ifdef __cplusplus
 }

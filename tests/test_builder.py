@@ -124,3 +124,24 @@ def test_degenerate_float_planes_veto_the_fast_tree(pkg):
     inf[7, 1] = np.inf
     i2 = pkg.Scene(pkg.scenes.SceneData(pos_nrm=inf, tri=sd.tri, tri_mesh=sd.tri_mesh, materials=sd.materials), device=-1).build_info()
     assert not i2["geometry_finite"] and not i2["fast_tree"]
+
+
+def test_threaded_builders_produce_the_sequential_arrays(pkg):
+    """The reference tree's levels, the leaf records, the in-leaf accelerators and the fast tree's top builder run on worker
+    threads (bvh_builder.cpp: the fast tree's subtrees are built into vectors of their own and stitched in the sequential build's
+    pre-order).  Every array the device reads must be the single-threaded build's, byte for byte, whatever the thread count."""
+    try:
+        for sd in (pkg.scenes.make_dragon(90_000), pkg.scenes.make_dragon_irregular(70_000), pkg.scenes.make_blob(9000, seed=3)):
+            hashes = []
+            for threads in (1, 2, 7, 0):
+                pkg.set_build_threads(threads)
+                sc = pkg.Scene(sd, device=-1)
+                sc.check_layout()
+                hashes.append((sc.layout_hash(), sc.num_subnodes(), sc.build_info()["fast_tree"]))
+                sc.close()
+            assert len(set(hashes)) == 1, hashes
+            assert hashes[0][2] is True
+    finally:
+        pkg.set_build_threads(0)
+    with pytest.raises(pkg.CgrtError):
+        pkg.set_build_threads(-1)

@@ -558,3 +558,43 @@ def test_dragon_800k_1080p_properties(pkg, orc):
     own0 = ~np.isnan(part[0]["t"])
     merged = np.where(own0, part[0], part[1])
     assert merged.tobytes() == hits.tobytes()
+
+
+@pytest.mark.parametrize("view", ["default", "zoomed"])
+def test_dodge_full_frame_800x800_primary_and_depth2(pkg, orc, scene_data, view):
+    """The largest real mesh the reference ships (data/dodgeColorTest.obj: 16 311 triangles in 11 meshes, arrays committed as
+    tests/golden/scenes/dodge.npz, un-normalised like the reference's Custom preset loads a model, scene.cpp:57-60) at the
+    reference's own window size (windowResolution{800, 800}, main.cpp:29), every pixel, from the default camera (main.cpp:730-731:
+    the car covers 3.5 % of the frame) and from the same trackball zoomed onto the car (distance 1, look-at = its centre: 25 %):
+    primary hits bit for bit (flag, t bits, primitive, material, normal bits) against the oracle in both kernel shapes and with the
+    exact walk, and the depth-2 frame (the reference's recursion cap, main.cpp:267) RGB within 1e-5 with equal ray counts."""
+    sd = scene_data("dodge")
+    W = H = 800
+    cam = np.asarray(pkg.scenes.default_camera(W, H), np.float32).copy()
+    if view == "zoomed":
+        cam[0:3] = [0.0712, 0.0169, 0.2369]
+        cam[6] = 1.0
+    o = orc.OracleScene(sd)
+    sc = pkg.Scene(sd)
+    rays = sc.generate_rays(cam, W, H)
+    assert np.array_equal(rays.view(np.float32).reshape(-1, 7).view(np.uint32), orc.generate_rays(cam, W, H).view(np.uint32))
+    ref = o.intersect(rays)
+    assert (0.02 if view == "default" else 0.15) < (ref["hit"] == 1).mean() < 0.95 and len(np.unique(ref["material"][ref["hit"] == 1])) >= 3
+    for shape in (0, 1):
+        pkg.set_kernel_shape(shape)
+        try:
+            hits, normals = sc.trace_primary(cam, W, H, want_normals=True)
+        finally:
+            pkg.set_kernel_shape(-1)
+        _assert_hits_equal(hits, normals, ref, f"dodge 800x800 {view} primary, kernel shape {shape}")
+    if sc.walk():
+        sc.set_walk(False)
+        hits, normals = sc.trace_primary(cam, W, H, want_normals=True)
+        _assert_hits_equal(hits, normals, ref, f"dodge 800x800 {view} primary, exact walk")
+        sc.set_walk(True)
+    rgb, st = sc.render(cam, W, H, max_level=2)
+    refrgb, nrays = o.render(cam, W, H, sd.point_lights, max_level=2)
+    err = np.abs(rgb.astype(np.float64) - refrgb).max()
+    assert err <= 1e-5, f"max abs RGB error {err}"  # BASELINE.json north_star: final pixel RGB within 1e-5 abs
+    assert st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"] == nrays and st["primary_rays"] == W * H
+    assert (refrgb.sum(1) > 0).mean() > 0.02
