@@ -107,8 +107,8 @@ _lib: Optional[C.CDLL] = None
 # every symbol include/cgrt.h declares
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_kernel_shape", "cgrt_get_kernel_shape", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_scene_build_info", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
-    "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
-    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_debug_layout_hash", "cgrt_set_build_threads", "cgrt_record_sizes",
+    "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_set_call_combining", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
+    "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_mapped", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_debug_layout_hash", "cgrt_set_build_threads", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version", "cgrt_source_hash",
 ]  # fmt: skip
@@ -155,6 +155,7 @@ def lib() -> C.CDLL:
     L.cgrt_device_bytes.restype = u64
     L.cgrt_intersect_batch.argtypes = [vp, vp, u64, vp, vp]
     L.cgrt_intersect_brute_batch.argtypes = [vp, vp, u64, i32, vp, vp]
+    L.cgrt_set_call_combining.argtypes = [i32]
     L.cgrt_intersect_batch_device.argtypes = [vp, vp, u64, vp, vp, vp]
     L.cgrt_trace_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp]
     L.cgrt_trace_primary_device.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp, vp]
@@ -162,6 +163,7 @@ def lib() -> C.CDLL:
     L.cgrt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats)]
     L.cgrt_render_counted.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, i32, vp, C.POINTER(RenderStats), C.POINTER(Counters)]
     L.cgrt_render_soft.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, vp, C.POINTER(RenderStats)]
+    L.cgrt_render_mapped.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, C.POINTER(vp), C.POINTER(RenderStats)]
     L.cgrt_render_rank.argtypes = [vp, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, i32, i32, vp, C.POINTER(RenderStats)]
     L.cgrt_trace_primary_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(Camera), i32, i32, vp, vp, C.POINTER(MultiStats)]
     L.cgrt_render_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(Camera), i32, i32, vp, u32, C.POINTER(SoftShadows), i32, vp, C.POINTER(RenderStats)]
@@ -233,8 +235,9 @@ def set_primary_mode(mode: int) -> None:
 
 
 def set_kernel_shape(mode: int = -1, max_rays: int = 0) -> None:
-    """-1 = by launch size (launches of at most max_rays rays take the quad-per-ray shape), 0 = lane per ray, 1 = quad per ray;
-    max_rays = 0 keeps the threshold.  Same results either way."""
+    """-1 = by launch size (short lists are laid out sparsely: include/cgrt.h), 0 = 64 rays per wave always, 1 = quad per ray
+    (16 per wave, frames too), 2 = 16 rays per wave for every list, 3 = 4 rays per wave for every list; max_rays = 0 keeps the
+    threshold.  Same results whatever the shape."""
     _check(lib().cgrt_set_kernel_shape(int(mode), int(max_rays)))
 
 
@@ -242,6 +245,11 @@ def kernel_shape() -> Tuple[int, int]:
     m, r = C.c_int(), C.c_uint64()
     _check(lib().cgrt_get_kernel_shape(C.byref(m), C.byref(r)))
     return int(m.value), int(r.value)
+
+
+def set_call_combining(enabled: bool = True) -> None:
+    """Small cgrt_intersect_batch calls of concurrent threads share one launch (default) or launch one by one; same results."""
+    _check(lib().cgrt_set_call_combining(1 if enabled else 0))
 
 
 def set_build_threads(threads: int = 0) -> None:
@@ -403,6 +411,17 @@ class Scene:
         st = RenderStats()
         c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
         _check(lib().cgrt_render(self._h, C.byref(c), W, H, _ptr(lights), len(lights), max_level, _ptr(rgb), C.byref(st)))
+        return rgb, {k: getattr(st, k) for k, _ in st._fields_}
+
+    def render_mapped(self, cam, W: int, H: int, lights=None, max_level: int = 2):
+        """cgrt_render_mapped: the frame stays in the scene's pinned staging memory; returns (a COPY of it as rgb[W*H,3], stats)
+        -- the copy is for the caller's convenience here, the C caller reads the pinned frame in place."""
+        lights = _f32(self.sd.point_lights if lights is None else lights, (-1, 6))
+        st = RenderStats()
+        ptr = C.c_void_p()
+        c = cam if isinstance(cam, Camera) else Camera.from_array(cam)
+        _check(lib().cgrt_render_mapped(self._h, C.byref(c), W, H, _ptr(lights), len(lights), None, max_level, C.byref(ptr), C.byref(st)))
+        rgb = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(W * H, 3)).copy()
         return rgb, {k: getattr(st, k) for k, _ in st._fields_}
 
     def render_counted(self, cam, W: int, H: int, lights=None, max_level: int = 2):
@@ -577,6 +596,8 @@ def host_lib() -> C.CDLL:
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
         H.cgrt_host_last_error.restype = C.c_char_p
         H.cgrt_host_render.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, vp, vp]
+        H.cgrt_host_time_screen_render.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, i32, vp]
+        H.cgrt_host_render_per_ray.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, i32, i32, i32, i32, vp, vp]
         H.cgrt_host_render_soft.argtypes = [vp, u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32, u32, vp, i32, i32, i32, vp, vp, i32]
         H.cgrt_host_load_obj.argtypes = [C.c_char_p, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp]
         H.cgrt_host_write_bmp.argtypes = [C.c_char_p, vp, i32, i32]
@@ -599,6 +620,36 @@ def host_render(sd: SceneData, cam, W: int, H: int, max_level: int = 2):
                              _ptr(camv), W, H, max_level, _ptr(rgb), _ptr(st))
     if rc:
         raise RuntimeError("cgrt_host_render: " + Hl.cgrt_host_last_error().decode())
+    return rgb, dict(primary=int(st[0]), shadow=int(st[1]), reflection=int(st[2]), seconds_device=float(st[3]), seconds_total=float(st[4]))
+
+
+def host_time_screen_render(sd: SceneData, cam, W: int, H: int, max_level: int = 2, reps: int = 5) -> dict:
+    """Whole-call milliseconds of the mirror's Screen-filling drivers (BVH built once): renderRayTracingOnDevice, renderRayTracing."""
+    Hl = host_lib()
+    pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+    tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
+    lights, camv = _f32(sd.point_lights, (-1, 6)), _f32(cam, (9,))
+    ms = np.zeros(3, np.float64)
+    rc = Hl.cgrt_host_time_screen_render(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(lights), len(lights),
+                                         _ptr(camv), W, H, max_level, reps, _ptr(ms))
+    if rc:
+        raise RuntimeError("cgrt_host_time_screen_render: " + Hl.cgrt_host_last_error().decode())
+    return dict(on_device_ms=float(ms[0]), host_wavefront_ms=float(ms[1]), on_device_device_share_ms=float(ms[2]))
+
+
+def host_render_per_ray(sd: SceneData, cam, W: int, H: int, max_level: int = 2, threads: int = 0):
+    """The reference's driver taken literally through the C++ mirror (renderToBufferPerRay): omp parallel for over rows, per-pixel
+    recursion, one BoundingVolumeHierarchy::intersect call per ray from `threads` threads. Returns (rgb[H*W,3], stats dict)."""
+    Hl = host_lib()
+    pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
+    tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
+    lights, camv = _f32(sd.point_lights, (-1, 6)), _f32(cam, (9,))
+    rgb = np.zeros((W * H, 3), np.float32)
+    st = np.zeros(5, np.float64)
+    rc = Hl.cgrt_host_render_per_ray(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(lights), len(lights),
+                                     _ptr(camv), W, H, max_level, threads, _ptr(rgb), _ptr(st))
+    if rc:
+        raise RuntimeError("cgrt_host_render_per_ray: " + Hl.cgrt_host_last_error().decode())
     return rgb, dict(primary=int(st[0]), shadow=int(st[1]), reflection=int(st[2]), seconds_device=float(st[3]), seconds_total=float(st[4]))
 
 

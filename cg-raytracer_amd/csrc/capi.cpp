@@ -35,6 +35,7 @@ thread_local std::string g_err;
 // under a mutex when a scene is created; the primary mode is read atomically by every launch.
 std::mutex g_options_mutex;
 BuildOptions g_build_options;
+std::atomic<int> g_call_combining{1};  // cgrt_set_call_combining
 std::atomic<int> g_primary_mode{0};  // 0 = one wave per tile, 1 = persistent waves with lane refill
 
 int fail(int code, const std::string& msg) {
@@ -174,6 +175,33 @@ struct CgrtScene {
     };
     std::mutex lanes_mutex;
     std::vector<CallLane*> lanes_free, lanes_all;
+    // Call combining (cgrt_intersect_batch with a handful of rays, i.e. BoundingVolumeHierarchy::intersect as the reference's
+    // `omp parallel for` issues it, main.cpp:653-656: one ray per call from many threads at once).  A launch per ray costs the
+    // GPU round trip per RAY; here concurrent callers append their rays to the open GENERATION of one of two pinned, device-mapped
+    // rings; the first caller of a generation is its leader: it closes the generation, launches ONE kernel over all its rays
+    // (the kernel reads the rays from and writes the hits to host memory directly: no copy commands), waits for that stream and
+    // publishes the results; the other callers wait on the generation's state and copy their own hits out.  While a generation
+    // is on the GPU the next one fills up, so the batch size adapts to the load.  Nothing stays resident on the device.
+    struct Combiner {
+        static const uint32_t CAP = 4096;   // rays per generation
+        static const uint32_t MAX_N = 64;   // calls with more rays than this take the direct path
+        enum State : int { FREE = 0, OPEN = 1, RUNNING = 2, DONE = 3 };
+        struct Ring {
+            void* host = nullptr;  // pinned + mapped: [CgrtRay x CAP | CgrtHit x CAP | normals 3 x CAP]
+            void* dev = nullptr;   // the same memory as the device sees it
+            hipStream_t stream = nullptr;
+            std::atomic<int> state{FREE};
+            uint32_t count = 0;        // rays appended (under mu)
+            uint32_t joined = 0;       // callers that appended (under mu)
+            std::atomic<uint32_t> readers_hint{0};  // = joined, readable without mu (the leader's grace period only)
+            std::atomic<uint32_t> readers{0};  // callers that still have to copy their results out
+            int rc = 0;                // the leader's status for the whole generation
+            std::string err;
+        } ring[2];
+        std::mutex mu;
+        std::atomic<int> inside{0};   // callers currently inside the combining entry (how many more may join a generation)
+        bool ready = false, failed = false;
+    } comb;
     std::mutex render_mutex;  // cgrt_render* share the workspace below: one frame per scene at a time
     unsigned persistent_blocks = 1024;  // 4 workgroups per CU
     // Device workspace of cgrt_render*: kept between frames (a frame of the same shape then allocates nothing; hipMalloc and
@@ -182,12 +210,21 @@ struct CgrtScene {
         void* p = nullptr;
         size_t cap = 0;
     } work[32];  // slots 0..28 are in use (render_impl)
+    // pinned host staging of cgrt_render*'s frame (grown on demand, guarded by render_mutex): the device frame comes down with ONE
+    // asynchronous copy at PCIe speed; cgrt_render_mapped hands this memory to the caller instead of copying it once more
+    void* pin_frame = nullptr;
+    size_t pin_frame_cap = 0;
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
         for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues})
             if (p) (void)hipFree(p);
+        if (pin_frame) (void)hipHostFree(pin_frame);
+        for (auto& r : comb.ring) {
+            if (r.host) (void)hipHostFree(r.host);
+            if (r.stream) (void)hipStreamDestroy(r.stream);
+        }
         for (CallLane* L : lanes_all) {
             for (auto& b : L->dev)
                 if (b.p) (void)hipFree(b.p);
@@ -379,7 +416,7 @@ int cgrt_set_primary_mode(int mode) {
     return CGRT_OK;
 }
 int cgrt_set_kernel_shape(int mode, uint64_t max_rays) {
-    if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (by launch size), 0 (lane per ray) or 1 (quad per ray)");
+    if (mode < -1 || mode > 3) return fail(CGRT_E_ARG, "mode must be -1 (by launch size), 0 (lane per ray, 64 per wave), 1 (quad per ray), 2 (lane per ray, 16 per wave) or 3 (4 rays per wave)");
     set_quad_shape(mode, max_rays);
     return CGRT_OK;
 }
@@ -708,10 +745,142 @@ int cgrt_intersect_batch_device(CgrtScene* s, const CgrtRay* d_rays, uint64_t n,
     return CGRT_OK;
 }
 
+namespace {
+inline void cpu_relax(unsigned& spins) {
+    if (++spins < 64)
+        __builtin_ia32_pause();
+    else
+        std::this_thread::yield();
+}
+// Returns 1 when the call was served by a combined generation (rc_out = its status), 0 when the caller should take the direct path.
+int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* hits, float* normals, int& rc_out) {
+    typedef CgrtScene::Combiner C;
+    C& cb = s->comb;
+    const size_t off_hits = sizeof(CgrtRay) * C::CAP, off_nrm = off_hits + sizeof(CgrtHit) * C::CAP, total = off_nrm + 12 * (size_t)C::CAP;
+    struct Inside {
+        std::atomic<int>& c;
+        explicit Inside(std::atomic<int>& x) : c(x) { c.fetch_add(1, std::memory_order_relaxed); }
+        ~Inside() { c.fetch_sub(1, std::memory_order_relaxed); }
+    } inside(cb.inside);
+    int b = -1;
+    uint32_t at = 0;
+    bool leader = false;
+    unsigned spins = 0;
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(cb.mu);
+            if (cb.failed) return 0;
+            if (!cb.ready) {  // first call on this scene: the two rings
+                if (hipSetDevice(s->device) != hipSuccess) {
+                    cb.failed = true;
+                    return 0;
+                }
+                for (auto& r : cb.ring) {
+                    hipError_t e = hipHostMalloc(&r.host, total, hipHostMallocMapped);
+                    if (e == hipSuccess) e = hipHostGetDevicePointer(&r.dev, r.host, 0);
+                    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
+                    if (e != hipSuccess) {
+                        cb.failed = true;  // (whatever was allocated is released with the scene)
+                        return 0;
+                    }
+                }
+                cb.ready = true;
+            }
+            // join the open generation, or open a free ring
+            for (int k = 0; k < 2 && b < 0; k++) {
+                C::Ring& r = cb.ring[k];
+                if (r.state.load(std::memory_order_acquire) == C::OPEN && r.count + n <= C::CAP) b = k;
+            }
+            for (int k = 0; k < 2 && b < 0; k++) {
+                C::Ring& r = cb.ring[k];
+                if (r.state.load(std::memory_order_acquire) == C::FREE) {
+                    r.count = 0;
+                    r.joined = 0;
+                    r.readers_hint.store(0, std::memory_order_relaxed);
+                    r.rc = 0;
+                    r.state.store(C::OPEN, std::memory_order_release);
+                    leader = true;
+                    b = k;
+                }
+            }
+            if (b >= 0) {
+                C::Ring& r = cb.ring[b];
+                at = r.count;
+                r.count += n;
+                r.joined += 1;
+                r.readers_hint.store(r.joined, std::memory_order_relaxed);
+                std::memcpy(static_cast<char*>(r.host) + sizeof(CgrtRay) * (size_t)at, rays, sizeof(CgrtRay) * (size_t)n);
+                break;
+            }
+        }
+        cpu_relax(spins);  // both rings are on the GPU or being read out: the next generation opens in a moment
+    }
+    C::Ring& r = cb.ring[b];
+    if (leader) {
+        // a short grace period while other callers are on their way in (they are already past the entry): a few hundred ns
+        // (callers parked on the other ring count as in: they are not coming)
+        for (unsigned k = 0; k < 200; k++) {
+            const C::Ring& o = cb.ring[b ^ 1];
+            const int parked = (o.state.load(std::memory_order_relaxed) != C::FREE) ? (int)o.readers_hint.load(std::memory_order_relaxed) : 0;
+            if ((int)r.readers_hint.load(std::memory_order_relaxed) + parked >= cb.inside.load(std::memory_order_relaxed)) break;
+            __builtin_ia32_pause();
+        }
+        uint32_t cnt;
+        {
+            std::lock_guard<std::mutex> lk(cb.mu);
+            r.state.store(C::RUNNING, std::memory_order_release);  // closed: later callers open the other ring
+            cnt = r.count;
+        }
+        int rc = CGRT_OK;
+        hipError_t e = hipSetDevice(s->device);
+        if (e == hipSuccess)
+            e = launch_trace_batch(s->dev, static_cast<const float*>(r.dev), cnt, reinterpret_cast<CgrtHitDev*>(static_cast<char*>(r.dev) + off_hits),
+                                   reinterpret_cast<float*>(static_cast<char*>(r.dev) + off_nrm), nullptr, r.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(r.stream);
+        if (e != hipSuccess) {
+            rc = CGRT_E_HIP;
+            r.err = std::string("combined launch: ") + hipGetErrorString(e);
+        }
+        r.rc = rc;
+        r.readers.store(r.joined, std::memory_order_relaxed);  // (joined is final: the generation was closed under mu)
+        r.state.store(C::DONE, std::memory_order_release);
+    } else {
+        unsigned sp = 0;
+        while (r.state.load(std::memory_order_acquire) != C::DONE) cpu_relax(sp);
+    }
+    rc_out = r.rc;
+    if (r.rc == CGRT_OK) {
+        const CgrtHit* rh = reinterpret_cast<const CgrtHit*>(static_cast<char*>(r.host) + off_hits) + at;
+        const float* rn = reinterpret_cast<const float*>(static_cast<char*>(r.host) + off_nrm) + 3 * (size_t)at;
+        std::memcpy(hits, rh, sizeof(CgrtHit) * (size_t)n);
+        if (normals)
+            for (uint32_t i = 0; i < n; i++)
+                if (rh[i].hit) std::memcpy(normals + 3 * (size_t)i, rn + 3 * (size_t)i, 12);  // HitInfo stays untouched on a miss
+    } else {
+        g_err = r.err;
+    }
+    if (r.readers.fetch_sub(1, std::memory_order_acq_rel) == 1) r.state.store(C::FREE, std::memory_order_release);  // last one out
+    return 1;
+}
+}  // namespace
+
+int cgrt_set_call_combining(int enabled) {
+    g_call_combining.store(enabled ? 1 : 0);
+    return CGRT_OK;
+}
+
 int cgrt_intersect_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtHit* hits, float* normals) {
     if (!s || (n && (!rays || !hits))) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     if (n == 0) return CGRT_OK;
+    if (n <= CgrtScene::Combiner::MAX_N && g_call_combining.load(std::memory_order_relaxed)) {
+        static const bool env_off = [] {
+            const char* e = getenv("CGRT_COMBINE");  // experiment knob: 0 = every call takes the direct path
+            return e && e[0] == '0';
+        }();
+        int rc = CGRT_OK;
+        if (!env_off && combined_intersect(s, rays, (uint32_t)n, hits, normals, rc)) return rc;
+    }
     HIP_TRY(hipSetDevice(s->device));
     LaneGuard g(s);
     int rc = g.acquire();
@@ -914,9 +1083,33 @@ int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters
 // renderRayTracing / getFinalColor (src/main.cpp:298-310, :648-720) as a device wavefront
 // counted (optional, 3 blocks): the frame is rendered with the instrumented kernels (never timed) and the work of its primary,
 // shadow and mirror traversals is returned separately
+namespace {
+// large host copies on a few threads (one thread moves ~10 GB/s: a 1080p float frame would take as long as 8 device frames)
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const size_t chunk = 4u << 20;
+    if (bytes < 2 * chunk) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const unsigned nt = (unsigned)std::min<size_t>(4, bytes / chunk);
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++)
+        pool.emplace_back([=] {
+            const size_t b = bytes * t / nt, e = bytes * (t + 1) / nt;
+            std::memcpy(static_cast<char*>(dst) + b, static_cast<const char*>(src) + b, e - b);
+        });
+    std::memcpy(dst, src, bytes / nt);
+    for (std::thread& th : pool) th.join();
+}
+}  // namespace
+
+// rgb (optional): the caller's frame; mapped (optional): receives the scene's pinned staging frame (valid until the next
+// cgrt_render* call on this scene).  With nranks > 1 only the pixels this rank owns are meaningful in the staging frame, and only
+// those are copied into rgb (pixels of other ranks keep the caller's contents).
 static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
-                       int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats, CgrtCounters* counted = nullptr) {
-    if (!s || !cam || !rgb || (nlights && !lights)) return fail(CGRT_E_ARG, "NULL argument");
+                       int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats, CgrtCounters* counted = nullptr,
+                       const float** mapped = nullptr) {
+    if (!s || !cam || (!rgb && !mapped) || (nlights && !lights)) return fail(CGRT_E_ARG, "NULL argument");
     NEED_DEVICE(s);
     if (W <= 0 || H <= 0 || max_level < 0 || max_level > 16) return fail(CGRT_E_ARG, "bad frame size or recursion depth");
     const unsigned SL = soft ? soft->nspherical : 0;
@@ -1007,7 +1200,6 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     bool finished = false;  // the frame's last kernels and its closing event have been issued inside the level loop
     std::vector<unsigned long long> level_count;  // entries per evaluated level
     HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
-    if (nranks > 1) HIP_TRY(hipMemcpy(drgb.p, rgb, npix * 12, hipMemcpyHostToDevice));  // pixels of other ranks keep caller data
     if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
         // level 0 = the primary rays that hit something, straight out of the fused primary kernel (pixels that miss are
         // black, main.cpp:293, and spawn nothing)
@@ -1137,7 +1329,30 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     HIP_TRY(hipEventElapsedTime(&ms, aux.e0, aux.e1));
     st.device_ms = ms;
     st.levels = nlev;
-    HIP_TRY(hipMemcpy(rgb, drgb.p, npix * 12, hipMemcpyDeviceToHost));
+    {
+        const size_t bytes = (size_t)npix * 12;
+        if (s->pin_frame_cap < bytes) {
+            if (s->pin_frame) (void)hipHostFree(s->pin_frame);
+            s->pin_frame = nullptr;
+            s->pin_frame_cap = 0;
+            HIP_TRY(hipHostMalloc(&s->pin_frame, bytes, hipHostMallocDefault));
+            s->pin_frame_cap = bytes;
+        }
+        HIP_TRY(hipMemcpyAsync(s->pin_frame, drgb.p, bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        const float* pin = static_cast<const float*>(s->pin_frame);
+        if (mapped) *mapped = pin;
+        if (rgb && nranks == 1) {
+            parallel_copy(rgb, pin, bytes);
+        } else if (rgb) {  // this rank's super-tiles only (the ownership rule of cgrt_trace_primary)
+            const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
+            for (uint64_t k = (uint64_t)rank; k < nst; k += (uint64_t)nranks) {
+                const int sx = (int)(k % (uint64_t)F.st_x) * 64, sy = (int)(k / (uint64_t)F.st_x) * 64;
+                const int w = std::min(64, W - sx), h = std::min(64, H - sy);
+                for (int r = 0; r < h; r++) std::memcpy(rgb + 3 * ((size_t)(sy + r) * W + sx), pin + 3 * ((size_t)(sy + r) * W + sx), (size_t)w * 12);
+            }
+        }
+    }
     if (counted) {
         unsigned long long h[24];
         HIP_TRY(hipMemcpy(h, dwork.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -1162,6 +1377,11 @@ int cgrt_render_counted(CgrtScene* s, const CgrtCamera* cam, int W, int H, const
 int cgrt_render_soft(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
                      int max_level, float* rgb, CgrtRenderStats* stats) {
     return render_impl(s, cam, W, H, lights, nlights, soft, max_level, 0, 1, rgb, stats);
+}
+int cgrt_render_mapped(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
+                       int max_level, const float** rgb, CgrtRenderStats* stats) {
+    if (!rgb) return fail(CGRT_E_ARG, "rgb is NULL");
+    return render_impl(s, cam, W, H, lights, nlights, soft, max_level, 0, 1, nullptr, stats, nullptr, rgb);
 }
 int cgrt_render_rank(CgrtScene* s, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights, const CgrtSoftShadows* soft,
                      int max_level, int rank, int nranks, float* rgb, CgrtRenderStats* stats) {
@@ -1307,20 +1527,13 @@ int cgrt_render_multi(CgrtScene* const* scenes, int nscenes, const CgrtCamera* c
     if (W <= 0 || H <= 0) return fail(CGRT_E_ARG, "bad frame size");
     // every replica renders its super-tiles (shading included: a pixel's secondary rays stay on the device that owns it) into a
     // frame of its own on a host thread of its own; the owned pixels are then merged into the caller's frame
-    const size_t npix = (size_t)W * H;
-    std::vector<std::vector<float>> frame(nscenes);
     std::vector<CgrtRenderStats> st(nscenes);
     std::vector<int> status(nscenes, CGRT_OK);
     std::vector<std::string> errs(nscenes);
     auto work = [&](int i) {
-        try {
-            frame[i].assign(npix * 3, 0.0f);
-        } catch (const std::bad_alloc&) {
-            status[i] = CGRT_E_ALLOC;
-            errs[i] = "host allocation failed";
-            return;
-        }
-        status[i] = render_impl(scenes[i], cam, W, H, lights, nlights, soft, max_level, i, nscenes, frame[i].data(), &st[i]);
+        // render_impl downloads the replica's frame into its scene's pinned staging and copies ONLY the super-tiles rank i owns
+        // into the caller's frame: disjoint regions, so the replicas' threads write rgb concurrently without a merge pass
+        status[i] = render_impl(scenes[i], cam, W, H, lights, nlights, soft, max_level, i, nscenes, rgb, &st[i]);
         if (status[i]) errs[i] = g_err;  // (thread-local: carried over to the caller's thread below)
     };
     {
@@ -1333,14 +1546,6 @@ int cgrt_render_multi(CgrtScene* const* scenes, int nscenes, const CgrtCamera* c
         if (status[i]) return fail(status[i], errs[i]);
     CgrtRenderStats tot{};
     for (int i = 0; i < nscenes; i++) {
-        FrameDev F;
-        make_frame(W, H, 0, 0, W, H, i, nscenes, CGRT_BLOCK, F);
-        const uint64_t nst = (uint64_t)F.st_x * (uint64_t)F.st_y;
-        for (uint64_t k = (uint64_t)i; k < nst; k += (uint64_t)nscenes) {
-            const int sx = (int)(k % (uint64_t)F.st_x) * 64, sy = (int)(k / (uint64_t)F.st_x) * 64;
-            const int w = std::min(64, W - sx), h = std::min(64, H - sy);
-            for (int r = 0; r < h; r++) std::memcpy(rgb + 3 * ((size_t)(sy + r) * W + sx), frame[i].data() + 3 * ((size_t)(sy + r) * W + sx), (size_t)w * 12);
-        }
         tot.primary_rays += st[i].primary_rays;
         tot.shadow_rays += st[i].shadow_rays;
         tot.reflection_rays += st[i].reflection_rays;

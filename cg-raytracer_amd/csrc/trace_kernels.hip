@@ -13,8 +13,11 @@
 
 #include "walk_quad.h"
 
-#ifndef CGRT_QUAD_MAX_RAYS_DEFAULT
-#define CGRT_QUAD_MAX_RAYS_DEFAULT 262144ull  // launches of at most this many rays take the quad shape (walk_quad.h); from measurements
+#ifndef CGRT_LANE16_MAX_RAYS_DEFAULT
+#define CGRT_LANE16_MAX_RAYS_DEFAULT 131072ull  // ray lists of at most this many rays: 16 rays per wave (see "kernel shape per launch")
+#endif
+#ifndef CGRT_QUAD4_MAX_RAYS_DEFAULT
+#define CGRT_QUAD4_MAX_RAYS_DEFAULT 8192ull  // ... of at most this many: 4 rays per wave, 16 lanes per ray (walk_quad.h)
 #endif
 
 namespace cgrt {
@@ -139,16 +142,23 @@ __global__ __launch_bounds__(CGRT_BLOCK) void k_clear_owned(FrameDev F, float* _
 template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays, unsigned long long n,
                                                             CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
-                                                            unsigned long long* counters, const uint32_t* __restrict__ dcount) {
+                                                            unsigned long long* counters, const uint32_t* __restrict__ dcount, unsigned qrpw, unsigned adapt_max) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     if (dcount) {
         const unsigned long long present = *dcount;
         n = present < n ? present : n;
     }
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long i = QUAD ? (g >> 2) : g;  // quad shape: the four lanes of a quad carry the same ray
+    // quad shape: the four lanes of a quad carry the same ray; a wave carries qrpw rays (16, or 4: the wide tail from the start)
+    // lane shape: one ray per lane; a SPARSE launch (single-wave workgroups with qrpw < 64 rays each) leaves the upper lanes of every
+    // wave empty, so that a wave of <= 16 rays runs the quad tail (four lanes per ray, four stack entries in flight) from its
+    // first step.  adapt_max (lists whose length only the device knows): sparse iff that length is at most adapt_max -- the grid
+    // covers both layouts.
+    if (!QUAD && adapt_max) qrpw = (n <= adapt_max) ? 16u : 64u;
+    const bool sparse = !QUAD && qrpw < 64u;
+    const unsigned long long i = QUAD ? ((unsigned long long)blockIdx.x * qrpw + (threadIdx.x >> 2)) : (sparse ? (unsigned long long)blockIdx.x * qrpw + threadIdx.x : g);
     const bool writer = !QUAD || (threadIdx.x & 3u) == 0u;
-    const bool active = i < n;
+    const bool active = i < n && (!QUAD || (threadIdx.x >> 2) < qrpw) && (!sparse || threadIdx.x < qrpw);
     LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     float t = 0.0f;
@@ -173,16 +183,18 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
 // hits[i] therefore holds a hit that decides the test like the reference's own, not necessarily the closest one.
 template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ rays, const float* __restrict__ dist, unsigned long long n,
-                                       CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount, unsigned long long* counters) {
+                                       CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount, unsigned long long* counters, unsigned qrpw, unsigned adapt_max) {
     extern __shared__ uint32_t s_lds[];
     if (dcount) {
         const unsigned long long present = *dcount;
         n = present < n ? present : n;
     }
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long i = QUAD ? (g >> 2) : g;
+    if (!QUAD && adapt_max) qrpw = (n <= adapt_max) ? 16u : 64u;  // (see k_trace_batch)
+    const bool sparse = !QUAD && qrpw < 64u;
+    const unsigned long long i = QUAD ? ((unsigned long long)blockIdx.x * qrpw + (threadIdx.x >> 2)) : (sparse ? (unsigned long long)blockIdx.x * qrpw + threadIdx.x : g);
     const bool writer = !QUAD || (threadIdx.x & 3u) == 0u;
-    const bool active = i < n;
+    const bool active = i < n && (!QUAD || (threadIdx.x >> 2) < qrpw) && (!sparse || threadIdx.x < qrpw);
     LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     float t = 0.0f, qlen = 0.0f;
@@ -302,33 +314,64 @@ int trace_block(const SceneDev& S) {
     hipLaunchKernelGGL((KERNEL<A, true, true>), dim3(grid), dim3(64), lds_bytes(64), stream, __VA_ARGS__)
 
 // ---- kernel shape per launch ----
-// Lane per ray (walk_fast.h) is the throughput shape; quad per ray (walk_quad.h) the latency shape: it spends four lanes on a
-// ray's set-up and certificate but walks a hard ray's chain ~1.5x faster and puts 16 rays in a wave instead of 64.  A launch
-// takes the quad shape when it is small enough that its time is the time of its hardest rays rather than the chip's throughput:
-// at most g_quad_max_rays rays (measured crossover, profiles/r3_exp_quad_shape.txt).  Results do not depend on the shape.
-static std::atomic<int> g_quad_mode{-1};                          // -1 = by size, 0 = never, 1 = whenever the scene has a fast tree
-static std::atomic<unsigned long long> g_quad_max_rays{CGRT_QUAD_MAX_RAYS_DEFAULT};
+// How a launch lays its rays out on the lanes (results never depend on it; tests/test_quad_shape_gpu.py):
+//   LANE64  one ray per lane, 64 per wave: the throughput shape (walk_fast.h), every frame and every large list;
+//   LANE16  one ray per lane, 16 rays per single-wave workgroup: the wave is in the quad tail -- four lanes per ray, four stack
+//           entries in flight -- from its first step, and a hard ray shares its wave with 15 others instead of 63;
+//   QUAD4   four rays per wave, a row of 16 lanes each: four stack entries x four child boxes per round (walk_quad.h);
+//   QUAD16  quad per ray, 16 rays per wave (walk_quad.h's basic shape; never chosen by size, kept selectable).
+// A launch ends when its hardest rays end, and a hard ray is a dependent chain that gets ~2x faster when it does not share its
+// wave's bodies with 63 others (profiles/r3_exp_list_shapes.txt: 64 hard rays 97 us as one wave, 51 us as four, 45 us as
+// sixteen) -- but sparse waves cost throughput, so the shape goes by the number of rays: <= g_quad4_max -> QUAD4,
+// <= g_lane16_max -> LANE16, else LANE64 (crossovers measured: 4 K rays 75 / 49 / 46 us, 16 K 84 / 56 / 60, 64 K 94 / 79 / 136,
+// 255 K 126 / 142 / 372 for LANE64 / LANE16 / QUAD4).  Lists whose length only the device knows (cgrt_render's wavefront) choose
+// between LANE64 and LANE16 on the device (adapt_max).  Frames keep LANE64: 71 % of a frame's waves die at the root gate and a
+// sparse shape pays its per-wave set-up four times for them (share of a 4K frame: 94 us -> 151 us, profiles/r3_exp_quad_shape.txt).
+enum { SHAPE_AUTO = -1, SHAPE_LANE64 = 0, SHAPE_QUAD16 = 1, SHAPE_LANE16 = 2, SHAPE_QUAD4 = 3 };
+static std::atomic<int> g_shape_mode{SHAPE_AUTO};
+static std::atomic<unsigned long long> g_lane16_max{CGRT_LANE16_MAX_RAYS_DEFAULT};
+static std::atomic<unsigned long long> g_quad4_max{CGRT_QUAD4_MAX_RAYS_DEFAULT};
 void set_quad_shape(int mode, unsigned long long max_rays) {
-    g_quad_mode.store(mode < 0 ? -1 : (mode ? 1 : 0));
-    if (max_rays) g_quad_max_rays.store(max_rays);
+    g_shape_mode.store((mode < 0 || mode > 3) ? SHAPE_AUTO : mode);
+    if (max_rays) {
+        g_lane16_max.store(max_rays);
+        g_quad4_max.store(std::min<unsigned long long>(max_rays, CGRT_QUAD4_MAX_RAYS_DEFAULT));
+    }
 }
 void get_quad_shape(int* mode, unsigned long long* max_rays) {
-    *mode = g_quad_mode.load();
-    *max_rays = g_quad_max_rays.load();
+    *mode = g_shape_mode.load();
+    *max_rays = g_lane16_max.load();
 }
-bool quad_shape_for(const SceneDev& S, unsigned long long rays) {
+static int shape_mode() {
     static const int env_mode = [] {
-        const char* e = getenv("CGRT_QUAD_MODE");  // experiment knob: -1 / 0 / 1
+        const char* e = getenv("CGRT_SHAPE");  // experiment knob: -1 auto / 0 lane64 / 1 quad16 / 2 lane16 / 3 quad4
         return e ? atoi(e) : -2;
     }();
-    static const unsigned long long env_max = [] {
-        const char* e = getenv("CGRT_QUAD_MAX_RAYS");
-        return e ? strtoull(e, nullptr, 10) : 0ull;
-    }();
-    if (S.fast_root == REF_NONE || trace_block(S) != 64) return false;
-    const int mode = env_mode != -2 ? env_mode : g_quad_mode.load();
-    if (mode >= 0) return mode != 0;
-    return rays <= (env_max ? env_max : g_quad_max_rays.load());
+    return env_mode != -2 ? env_mode : g_shape_mode.load();
+}
+static unsigned long long env_ull(const char* name) {
+    const char* e = getenv(name);
+    return e ? strtoull(e, nullptr, 10) : 0ull;
+}
+// shape of a ray LIST of n rays (n known to the host)
+static int list_shape(const SceneDev& S, unsigned long long n) {
+    if (S.fast_root == REF_NONE || trace_block(S) != 64) return SHAPE_LANE64;
+    const int mode = shape_mode();
+    if (mode != SHAPE_AUTO) return mode;
+    static const unsigned long long e16 = env_ull("CGRT_LANE16_MAX"), e4 = env_ull("CGRT_QUAD4_MAX");
+    if (n <= (e4 ? e4 : g_quad4_max.load())) return SHAPE_QUAD4;
+    if (n <= (e16 ? e16 : g_lane16_max.load())) return SHAPE_LANE16;
+    return SHAPE_LANE64;
+}
+// lists sized on the device: 0 = the host's choice stands, else "LANE16 iff the device count is at most this"
+static unsigned list_adapt_max(const SceneDev& S, const uint32_t* dcount) {
+    if (!dcount || S.fast_root == REF_NONE || trace_block(S) != 64 || shape_mode() != SHAPE_AUTO) return 0u;
+    static const unsigned long long e16 = env_ull("CGRT_LANE16_MAX");
+    return (unsigned)std::min<unsigned long long>(e16 ? e16 : g_lane16_max.load(), 0x7fffffffull);
+}
+bool quad_shape_for(const SceneDev& S, unsigned long long rays) {  // frames: the quad shape only when forced
+    (void)rays;
+    return S.fast_root != REF_NONE && trace_block(S) == 64 && shape_mode() == SHAPE_QUAD16;
 }
 
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
@@ -348,42 +391,55 @@ hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const Fra
         CGRT_LAUNCH2(k_trace_primary, false, fast, F.nblocks, (unsigned)F.block, stream, S, C, F, hits, normals, counters);
     return hipGetLastError();
 }
+// grid of a list launch in the lane shapes: covers 64 rays per workgroup, and 16 per workgroup up to the adaptive bound
+static unsigned lane_grid(unsigned long long n, unsigned block, unsigned rpw, unsigned adapt_max) {
+    if (adapt_max) return std::max(grid_for(n, block), grid_for(std::min<unsigned long long>(n, adapt_max), 16));
+    return grid_for(n, rpw < 64u ? rpw : block);
+}
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
                               unsigned long long* counters, hipStream_t stream, const uint32_t* dcount) {
     if (n == 0) return hipSuccess;
     const unsigned block = (unsigned)trace_block(S);
-    const unsigned blocks = grid_for(n, block);
     const bool fast = S.fast_root != REF_NONE;
-    if (quad_shape_for(S, n)) {
+    const unsigned adapt = list_adapt_max(S, dcount);
+    const int shape = adapt ? SHAPE_LANE64 : list_shape(S, n);
+    if (shape == SHAPE_QUAD16 || shape == SHAPE_QUAD4) {
+        const unsigned q = shape == SHAPE_QUAD4 ? 4u : 16u;
         if (counters)
-            CGRT_LAUNCHQ(k_trace_batch, true, grid_for(4ull * n, 64), stream, S, rays, n, hits, normals, counters, dcount);
+            CGRT_LAUNCHQ(k_trace_batch, true, grid_for(n, q), stream, S, rays, n, hits, normals, counters, dcount, q, 0u);
         else
-            CGRT_LAUNCHQ(k_trace_batch, false, grid_for(4ull * n, 64), stream, S, rays, n, hits, normals, counters, dcount);
+            CGRT_LAUNCHQ(k_trace_batch, false, grid_for(n, q), stream, S, rays, n, hits, normals, counters, dcount, q, 0u);
         return hipGetLastError();
     }
+    const unsigned rpw = shape == SHAPE_LANE16 ? 16u : 64u;
+    const unsigned grid = lane_grid(n, block, rpw, adapt);
     if (counters)
-        CGRT_LAUNCH2(k_trace_batch, true, fast, blocks, block, stream, S, rays, n, hits, normals, counters, dcount);
+        CGRT_LAUNCH2(k_trace_batch, true, fast, grid, block, stream, S, rays, n, hits, normals, counters, dcount, rpw, adapt);
     else
-        CGRT_LAUNCH2(k_trace_batch, false, fast, blocks, block, stream, S, rays, n, hits, normals, counters, dcount);
+        CGRT_LAUNCH2(k_trace_batch, false, fast, grid, block, stream, S, rays, n, hits, normals, counters, dcount, rpw, adapt);
     return hipGetLastError();
 }
 hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
                                const uint32_t* dcount, unsigned long long* counters) {
     if (n == 0) return hipSuccess;
     const unsigned block = (unsigned)trace_block(S);
-    const unsigned blocks = grid_for(n, block);
     const bool fast = S.fast_root != REF_NONE;
-    if (quad_shape_for(S, n)) {
+    const unsigned adapt = list_adapt_max(S, dcount);
+    const int shape = adapt ? SHAPE_LANE64 : list_shape(S, n);
+    if (shape == SHAPE_QUAD16 || shape == SHAPE_QUAD4) {
+        const unsigned q = shape == SHAPE_QUAD4 ? 4u : 16u;
         if (counters)
-            CGRT_LAUNCHQ(k_trace_shadow, true, grid_for(4ull * n, 64), stream, S, rays, dist, n, hits, dcount, counters);
+            CGRT_LAUNCHQ(k_trace_shadow, true, grid_for(n, q), stream, S, rays, dist, n, hits, dcount, counters, q, 0u);
         else
-            CGRT_LAUNCHQ(k_trace_shadow, false, grid_for(4ull * n, 64), stream, S, rays, dist, n, hits, dcount, counters);
+            CGRT_LAUNCHQ(k_trace_shadow, false, grid_for(n, q), stream, S, rays, dist, n, hits, dcount, counters, q, 0u);
         return hipGetLastError();
     }
+    const unsigned rpw = shape == SHAPE_LANE16 ? 16u : 64u;
+    const unsigned grid = lane_grid(n, block, rpw, adapt);
     if (counters)
-        CGRT_LAUNCH2(k_trace_shadow, true, fast, blocks, block, stream, S, rays, dist, n, hits, dcount, counters);
+        CGRT_LAUNCH2(k_trace_shadow, true, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt);
     else
-        CGRT_LAUNCH2(k_trace_shadow, false, fast, blocks, block, stream, S, rays, dist, n, hits, dcount, counters);
+        CGRT_LAUNCH2(k_trace_shadow, false, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,

@@ -42,6 +42,15 @@ RenderStats renderToBufferOnDevices(const Scene& scene, const Trackball& camera,
                                     float* rgb, int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
 RenderStats renderRayTracingOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs,
                                       Screen& screen, int maxLevel = 2, const SoftShadowSampler* sampler = nullptr);
+// The reference's driver LITERALLY (src/main.cpp:265-310, :648-696): an `omp parallel for` over the rows, per pixel the recursive
+// getFinalColor -> trace -> shade -> shading -> pointInShadow, ONE BoundingVolumeHierarchy::intersect call per ray -- what an
+// unchanged main.cpp does to the library.  The library combines the rays of concurrent callers into shared launches
+// (include/cgrt.h cgrt_set_call_combining), so the frame's speed grows with the number of calling threads; `threads` = 0 takes
+// OpenMP's default, and MORE threads than cores pay: a caller spends its time waiting for the GPU round trip.
+RenderStats renderToBufferPerRay(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
+                                 int maxLevel = 2, const SoftShadowSampler* sampler = nullptr, int threads = 0);
+RenderStats renderRayTracingPerRay(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel = 2,
+                                   const SoftShadowSampler* sampler = nullptr, int threads = 0);
 // sampler: required when the scene has spherical lights (nullptr -> SoftShadowSampler::gaussian()).
 RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel = 2,
                              const SoftShadowSampler* sampler = nullptr);

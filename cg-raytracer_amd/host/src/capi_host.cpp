@@ -1,5 +1,6 @@
 // C entry points of the host mirror for the Python test harness (ctypes): build a Scene from flat arrays or from
 // an OBJ file, run the wavefront render driver, dump a loaded scene back to flat arrays.
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -66,6 +67,67 @@ int cgrt_host_render(const float* pos_nrm, uint32_t nverts, const uint32_t* tri,
             stats[2] = (double)st.reflection;
             stats[3] = st.seconds_device;
             stats[4] = st.seconds_total;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// The same frame through the reference's driver taken literally (renderToBufferPerRay: omp parallel for over rows, per-pixel
+// recursion, ONE BoundingVolumeHierarchy::intersect call per ray) with `threads` caller threads (0 = OpenMP's default).
+int cgrt_host_render_per_ray(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
+                             const float* materials, uint32_t nmesh, const float* lights, uint32_t nlights, const float* cam, int W, int H,
+                             int maxLevel, int threads, float* rgb, double* stats) {
+    try {
+        Scene sc = scene_from_arrays(pos_nrm, nverts, tri, tri_mesh, ntris, materials, nmesh, lights, nlights);
+        BoundingVolumeHierarchy bvh(&sc);
+        Trackball camera(cam[7], cam[8], cam[6]);
+        camera.setCamera(cgrt::vec3(cam[0], cam[1], cam[2]), cgrt::vec3(cam[3], cam[4], cam[5]), cam[6]);
+        RenderStats st = renderToBufferPerRay(sc, camera, bvh, W, H, rgb, maxLevel, nullptr, threads);
+        if (stats) {
+            stats[0] = (double)st.primary;
+            stats[1] = (double)st.shadow;
+            stats[2] = (double)st.reflection;
+            stats[3] = st.seconds_device;
+            stats[4] = st.seconds_total;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Whole-call times of the mirror's drivers that fill a Screen (what a caller of renderRayTracing* waits for), BVH built once:
+// ms[0] = renderRayTracingOnDevice (device driver -> pinned frame -> Screen::setFrame), ms[1] = renderRayTracing (host-driven
+// wavefront), each the best of `reps` calls; ms[2] = device share of the best OnDevice call.
+int cgrt_host_time_screen_render(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
+                                 const float* materials, uint32_t nmesh, const float* lights, uint32_t nlights, const float* cam, int W, int H,
+                                 int maxLevel, int reps, double* ms) {
+    try {
+        Scene sc = scene_from_arrays(pos_nrm, nverts, tri, tri_mesh, ntris, materials, nmesh, lights, nlights);
+        BoundingVolumeHierarchy bvh(&sc);
+        Trackball camera(cam[7], cam[8], cam[6]);
+        camera.setCamera(cgrt::vec3(cam[0], cam[1], cam[2]), cgrt::vec3(cam[3], cam[4], cam[5]), cam[6]);
+        Screen screen(W, H);
+        using Clk = std::chrono::steady_clock;
+        ms[0] = ms[1] = 1e30;
+        ms[2] = 0;
+        for (int r = 0; r < reps + 1; r++) {  // (the first call grows the library's workspaces)
+            const auto t0 = Clk::now();
+            const RenderStats st = renderRayTracingOnDevice(sc, camera, bvh, screen, maxLevel);
+            const double t = std::chrono::duration<double, std::milli>(Clk::now() - t0).count();
+            if (r > 0 && t < ms[0]) {
+                ms[0] = t;
+                ms[2] = st.seconds_device * 1e3;
+            }
+        }
+        for (int r = 0; r < reps; r++) {
+            const auto t0 = Clk::now();
+            (void)renderRayTracing(sc, camera, bvh, screen, maxLevel);
+            ms[1] = std::min(ms[1], std::chrono::duration<double, std::milli>(Clk::now() - t0).count());
         }
         return 0;
     } catch (const std::exception& e) {

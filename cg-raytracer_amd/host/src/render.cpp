@@ -3,6 +3,8 @@
 
 #include "../../../include/cgrt.h"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -251,8 +253,12 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
     return st;
 }
 
-RenderStats renderToBufferOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs, int W, int H,
-                                    float* rgb, int maxLevel, const SoftShadowSampler* sampler) {
+namespace {
+// The whole driver on the device(s).  rgb != nullptr: the frame goes into the caller's buffer; screen != nullptr: into the
+// Screen (Screen::setPixel's flip, main.cpp:696) -- with one replica straight from the library's pinned frame
+// (cgrt_render_mapped: no intermediate copy of the 12-bytes-per-pixel frame), rows copied in bulk (Screen::setFrame).
+RenderStats render_on_devices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs, int W, int H,
+                              float* rgb, Screen* screen, int maxLevel, const SoftShadowSampler* sampler) {
     const auto t_begin = Clock::now();
     if (bvhs.empty()) throw std::runtime_error("renderToBufferOnDevices: no BVH replica");
     SoftShadowSampler fallback;
@@ -280,11 +286,24 @@ RenderStats renderToBufferOnDevices(const Scene& scene, const Trackball& camera,
     const CgrtCamera cam = camera.abi();
     std::vector<CgrtScene*> handles;
     for (const BoundingVolumeHierarchy* b : bvhs) handles.push_back(b->handle());
-    const int rc = handles.size() == 1
-                       ? cgrt_render_soft(handles[0], &cam, W, H, lights.data(), (uint32_t)scene.pointLights.size(), spherical.empty() ? nullptr : &soft,
-                                          maxLevel, rgb, &cs)
-                       : cgrt_render_multi(handles.data(), (int)handles.size(), &cam, W, H, lights.data(), (uint32_t)scene.pointLights.size(),
-                                           spherical.empty() ? nullptr : &soft, maxLevel, rgb, &cs);
+    const uint32_t L = (uint32_t)scene.pointLights.size();
+    const CgrtSoftShadows* sp = spherical.empty() ? nullptr : &soft;
+    int rc;
+    if (handles.size() == 1 && screen) {
+        const float* frame = nullptr;
+        rc = cgrt_render_mapped(handles[0], &cam, W, H, lights.data(), L, sp, maxLevel, &frame, &cs);
+        if (rc == 0) screen->setFrame(frame);
+    } else if (handles.size() == 1) {
+        rc = cgrt_render_soft(handles[0], &cam, W, H, lights.data(), L, sp, maxLevel, rgb, &cs);
+    } else {
+        std::vector<float> tmp;
+        if (!rgb) {
+            tmp.resize((size_t)W * H * 3);
+            rgb = tmp.data();
+        }
+        rc = cgrt_render_multi(handles.data(), (int)handles.size(), &cam, W, H, lights.data(), L, sp, maxLevel, rgb, &cs);
+        if (rc == 0 && screen) screen->setFrame(rgb);
+    }
     if (rc != 0) throw std::runtime_error(std::string("cgrt_render: ") + cgrt_last_error());
     RenderStats st;
     st.primary = cs.primary_rays;
@@ -295,35 +314,135 @@ RenderStats renderToBufferOnDevices(const Scene& scene, const Trackball& camera,
     st.seconds_total = std::chrono::duration<double>(Clock::now() - t_begin).count();
     return st;
 }
+}  // namespace
+
+RenderStats renderToBufferOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs, int W, int H,
+                                    float* rgb, int maxLevel, const SoftShadowSampler* sampler) {
+    return render_on_devices(scene, camera, bvhs, W, H, rgb, nullptr, maxLevel, sampler);
+}
 
 RenderStats renderToBufferOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
                                    int maxLevel, const SoftShadowSampler* sampler) {
-    return renderToBufferOnDevices(scene, camera, {&bvh}, W, H, rgb, maxLevel, sampler);
+    return render_on_devices(scene, camera, {&bvh}, W, H, rgb, nullptr, maxLevel, sampler);
 }
 
 RenderStats renderRayTracingOnDevices(const Scene& scene, const Trackball& camera, const std::vector<const BoundingVolumeHierarchy*>& bvhs,
                                       Screen& screen, int maxLevel, const SoftShadowSampler* sampler) {
-    const int W = screen.width(), H = screen.height();
-    std::vector<float> rgb((size_t)W * H * 3);
-    RenderStats st = renderToBufferOnDevices(scene, camera, bvhs, W, H, rgb.data(), maxLevel, sampler);
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
-            const float* p = &rgb[3 * ((size_t)y * W + x)];
-            screen.setPixel(x, y, cgrt::vec3(p[0], p[1], p[2]));  // main.cpp:696
-        }
-    return st;
+    return render_on_devices(scene, camera, bvhs, screen.width(), screen.height(), nullptr, &screen, maxLevel, sampler);
 }
 
 RenderStats renderRayTracingOnDevice(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel,
                                      const SoftShadowSampler* sampler) {
+    return render_on_devices(scene, camera, {&bvh}, screen.width(), screen.height(), nullptr, &screen, maxLevel, sampler);
+}
+
+// ---- the reference's per-pixel recursion, one intersect call per ray (main.cpp:104-135, :160-310, :648-696) ----
+namespace {
+struct PerRay {
+    const Scene& scene;
+    const BoundingVolumeHierarchy& bvh;
+    const SoftShadowSampler* sampler;
+    int maxLevel;
+    // pointInShadow, main.cpp:104-135
+    bool pointInShadow(const vec3& pointOn, const vec3& fromPosToLight, uint64_t& nshadow) const {
+        const float eps = 0.001;
+        Ray shadowRay{pointOn, cgrt::normalize(fromPosToLight), std::numeric_limits<float>::max()};
+        shadowRay.origin = shadowRay.origin + eps * shadowRay.direction;
+        HitInfo tmp;
+        nshadow++;
+        if (bvh.intersect(shadowRay, tmp)) return !(shadowRay.t + eps >= cgrt::length(fromPosToLight));  // :118-130
+        return false;
+    }
+    // shading, main.cpp:160-235: spherical lights first (soft shadows), then the point lights
+    vec3 shading(const Ray& ray, const HitInfo& hitInfo, uint32_t pixel, int level, uint64_t& nshadow, uint64_t& nsoft) const {
+        const vec3 pointOn = ray.origin + ray.direction * ray.t;
+        vec3 result(0.0f);
+        for (size_t l = 0; l < scene.sphericalLight.size(); l++) {
+            const SphericalLight& spherical = scene.sphericalLight[l];
+            const PointLight light{spherical.position, spherical.color};
+            const vec3 fromPosToLight = cgrt::normalize(light.position - pointOn);
+            const vec3 diffuse = diffuseOneLight(light, fromPosToLight, hitInfo);
+            const vec3 specular = specularOneLight(ray, light, fromPosToLight, hitInfo);
+            uint32_t lit = 0;
+            for (uint32_t k = 0; k < sampler->samples; k++) {
+                const vec3 randomPointOnSphere = spherical.position + spherical.radius * sampler->draw(pixel, (uint32_t)level, (uint32_t)l, k);
+                Ray newRay;
+                newRay.origin = pointOn + (float)(0.001) * cgrt::normalize(randomPointOnSphere - pointOn);
+                newRay.direction = cgrt::normalize(randomPointOnSphere - pointOn);
+                newRay.t = cgrt::length(newRay.origin - randomPointOnSphere);
+                const float lightT = cgrt::length(newRay.origin - randomPointOnSphere);
+                HitInfo hi;
+                nsoft++;
+                if (!bvh.intersect(newRay, hi) || newRay.t > lightT) lit++;
+            }
+            const float softShadowCounter = (float)lit / (float)sampler->samples;
+            result += diffuse * softShadowCounter;
+            result += specular * softShadowCounter;
+        }
+        for (const PointLight& light : scene.pointLights) {
+            const vec3 toLight = light.position - pointOn;
+            const vec3 fromPosToLight = cgrt::normalize(toLight);
+            if (pointInShadow(pointOn, toLight, nshadow)) continue;
+            result += diffuseOneLight(light, fromPosToLight, hitInfo);
+            result += specularOneLight(ray, light, fromPosToLight, hitInfo);
+        }
+        return result;
+    }
+    // trace + shade, main.cpp:241-295
+    vec3 trace(int level, Ray ray, uint32_t pixel, uint64_t& nshadow, uint64_t& nrefl, uint64_t& nsoft) const {
+        if (level >= maxLevel) return vec3(0.0f);  // :267
+        HitInfo hitInfo;
+        if (level > 0) nrefl++;
+        if (!bvh.intersect(ray, hitInfo)) return vec3(0.0f);  // :293
+        const vec3 color = shading(ray, hitInfo, pixel, level, nshadow, nsoft);
+        if (hitInfo.material.ks.z <= 0.01f) return color;  // :246 (the comma operator leaves ks.z)
+        if (level + 1 >= maxLevel) return color;            // trace(level + 1) is black: color + 0 * ks
+        const float eps = 0.001;
+        const vec3 pointOn = ray.origin + ray.direction * ray.t;
+        Ray reflected{pointOn, cgrt::normalize(cgrt::reflect(ray.direction, hitInfo.normal)), cgrt::length(ray.direction)};  // :254
+        reflected.origin = reflected.origin + eps * reflected.direction;
+        const vec3 reflectedColor = trace(level + 1, reflected, pixel, nshadow, nrefl, nsoft);
+        return color + reflectedColor * hitInfo.material.ks;  // :262
+    }
+};
+}  // namespace
+
+RenderStats renderToBufferPerRay(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb, int maxLevel,
+                                 const SoftShadowSampler* sampler, int threads) {
+    RenderStats st;
+    SoftShadowSampler fallback;
+    if (!scene.sphericalLight.empty() && (!sampler || sampler->units.empty() || sampler->samples == 0)) {
+        fallback = SoftShadowSampler::gaussian();
+        sampler = &fallback;
+    }
+    const auto t_begin = Clock::now();
+    const PerRay drv{scene, bvh, sampler, maxLevel};
+    uint64_t nshadow = 0, nrefl = 0, nsoft = 0;
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : nshadow, nrefl, nsoft)
+    for (int y = 0; y < H; y++) {  // main.cpp:653-656
+        for (int x = 0; x < W; x++) {
+            const cgrt::vec2 normalizedPixelPos{float(x) / W * 2.0f - 1.0f, float(y) / H * 2.0f - 1.0f};  // :691-693
+            const Ray cameraRay = camera.generateRay(normalizedPixelPos);
+            const vec3 c = drv.trace(0, cameraRay, (uint32_t)(y * W + x), nshadow, nrefl, nsoft);
+            float* p = rgb + 3 * ((size_t)y * W + x);
+            p[0] = c.x, p[1] = c.y, p[2] = c.z;
+        }
+    }
+    st.primary = maxLevel >= 1 ? (uint64_t)W * H : 0;
+    st.shadow = nshadow;
+    st.reflection = nrefl;
+    st.softShadow = nsoft;
+    st.seconds_total = st.seconds_device = std::chrono::duration<double>(Clock::now() - t_begin).count();
+    return st;
+}
+
+RenderStats renderRayTracingPerRay(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel,
+                                   const SoftShadowSampler* sampler, int threads) {
     const int W = screen.width(), H = screen.height();
     std::vector<float> rgb((size_t)W * H * 3);
-    RenderStats st = renderToBufferOnDevice(scene, camera, bvh, W, H, rgb.data(), maxLevel, sampler);
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
-            const float* p = &rgb[3 * ((size_t)y * W + x)];
-            screen.setPixel(x, y, cgrt::vec3(p[0], p[1], p[2]));  // main.cpp:696
-        }
+    RenderStats st = renderToBufferPerRay(scene, camera, bvh, W, H, rgb.data(), maxLevel, sampler, threads);
+    screen.setFrame(rgb.data());  // main.cpp:696 for every pixel
     return st;
 }
 
@@ -332,10 +451,6 @@ RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const 
     const int W = screen.width(), H = screen.height();
     std::vector<float> rgb((size_t)W * H * 3);
     RenderStats st = renderToBuffer(scene, camera, bvh, W, H, rgb.data(), maxLevel, sampler);
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
-            const float* p = &rgb[3 * ((size_t)y * W + x)];
-            screen.setPixel(x, y, cgrt::vec3(p[0], p[1], p[2]));  // main.cpp:696
-        }
+    screen.setFrame(rgb.data());  // main.cpp:696 for every pixel
     return st;
 }

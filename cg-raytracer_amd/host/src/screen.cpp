@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <fstream>
+#include <thread>
 
 void Screen::writeBitmapToFile(const std::filesystem::path& filePath) const {
     const int rowBytes = (m_w * 3 + 3) & ~3;
@@ -31,4 +33,17 @@ void Screen::writeBitmapToFile(const std::filesystem::path& filePath) const {
         }
         f.write(reinterpret_cast<const char*>(row.data()), rowBytes);
     }
+}
+
+void Screen::setFrame(const float* rgb) {
+    static_assert(sizeof(cgrt::vec3) == 12, "vec3 is three packed floats");
+    auto rows = [&](int y0, int y1) {
+        for (int y = y0; y < y1; y++) std::memcpy(static_cast<void*>(&m_data[(size_t)(m_h - 1 - y) * m_w]), rgb + 3 * (size_t)y * m_w, (size_t)m_w * 12);
+    };
+    const size_t bytes = (size_t)m_w * m_h * 12;
+    const int nt = bytes < (8u << 20) ? 1 : 4;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(rows, m_h * t / nt, m_h * (t + 1) / nt);
+    rows(0, m_h / nt);
+    for (std::thread& th : pool) th.join();
 }

@@ -1,9 +1,12 @@
 // Headless stand-in for the reference's interactive main() (src/main.cpp:722-939): load a scene preset or an OBJ,
 // build the BVH, render with the reference's default camera, write render.bmp, print the timing the reference prints
 // (main.cpp:791-797).
-//   render [--gpus N] <data-dir> <triangle|cube|cornell|monkey|dragon|custom|file.obj> [W H [maxLevel [out.bmp]]]
+//   render [--gpus N | --per-ray [--threads T]] <data-dir> <triangle|cube|cornell|monkey|dragon|custom|file.obj> [W H [maxLevel [out.bmp]]]
 // --gpus N: the frame is split over N devices (replica i on device i % cgrt_device_count(), super-tiles i % N), the whole
 // shading driver on the devices, one Screen (renderRayTracingOnDevices).
+// --per-ray: the reference's own structure, literally (main.cpp:265-310, :648-696): `omp parallel for` over rows, per-pixel
+// recursive getFinalColor, ONE bvh.intersect call per ray from T threads (default: OpenMP's) -- what an unchanged main.cpp does
+// to the library; concurrent calls share launches inside it (cgrt_set_call_combining).
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -15,14 +18,27 @@
 extern "C" int cgrt_device_count(void);
 
 int main(int argc, char** argv) {
-    int gpus = 0;
-    if (argc > 2 && std::strcmp(argv[1], "--gpus") == 0) {
-        gpus = std::atoi(argv[2]);
-        argv += 2;
-        argc -= 2;
+    int gpus = 0, threads = 0;
+    bool perRay = false;
+    for (;;) {
+        if (argc > 2 && std::strcmp(argv[1], "--gpus") == 0) {
+            gpus = std::atoi(argv[2]);
+            argv += 2;
+            argc -= 2;
+        } else if (argc > 1 && std::strcmp(argv[1], "--per-ray") == 0) {
+            perRay = true;
+            argv += 1;
+            argc -= 1;
+        } else if (argc > 2 && std::strcmp(argv[1], "--threads") == 0) {
+            threads = std::atoi(argv[2]);
+            argv += 2;
+            argc -= 2;
+        } else {
+            break;
+        }
     }
     if (argc < 3) {
-        std::cerr << "usage: render [--gpus N] <data-dir> <scene|file.obj> [W H [maxLevel [out.bmp]]]\n";
+        std::cerr << "usage: render [--gpus N | --per-ray [--threads T]] <data-dir> <scene|file.obj> [W H [maxLevel [out.bmp]]]\n";
         return 2;
     }
     const std::filesystem::path dataDir = argv[1];
@@ -53,7 +69,9 @@ int main(int argc, char** argv) {
         // CGRT_RENDER_ON_DEVICE=1: the whole shading/recursion driver on the GPU instead of the host-driven wavefront
         const char* od = std::getenv("CGRT_RENDER_ON_DEVICE");
         RenderStats st;
-        if (gpus > 0) {
+        if (perRay) {
+            st = renderRayTracingPerRay(scene, camera, bvh, screen, maxLevel, nullptr, threads);
+        } else if (gpus > 0) {
             const int ndev = cgrt_device_count() > 0 ? cgrt_device_count() : 1;
             std::vector<std::unique_ptr<BoundingVolumeHierarchy>> own;
             std::vector<const BoundingVolumeHierarchy*> bvhs;

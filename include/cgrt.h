@@ -15,7 +15,9 @@
  *   - cgrt_intersect_batch, cgrt_trace_primary, cgrt_generate_rays, cgrt_count_* (host pointers) may be called
  *     concurrently on ONE scene from any number of threads: each call runs on a private stream with private device
  *     scratch and pinned staging taken from a per-scene pool and waits for that stream only (no hipMalloc / hipFree /
- *     hipDeviceSynchronize once the pool has grown to the call sizes in use);
+ *     hipDeviceSynchronize once the pool has grown to the call sizes in use); cgrt_intersect_batch calls of at most 64 rays --
+ *     BoundingVolumeHierarchy::intersect, one ray per call -- are COMBINED: concurrent callers append their rays to a shared
+ *     pinned ring, one of them launches one kernel for all of them and everybody copies its own hits out (cgrt_set_call_combining);
  *   - the *_device entries only enqueue work on the caller's stream and touch no mutable scene state: concurrent too;
  *   - cgrt_render* use one per-scene workspace: calls on the same scene are serialised by a mutex inside the library;
  *   - cgrt_set_* are process-wide options (mutex / atomic inside); cgrt_scene_set_walk and cgrt_scene_destroy must not
@@ -110,11 +112,16 @@ int cgrt_num_subnodes(const CgrtScene* scene);
 /* Scheduling of the fused primary-frame kernel (results are identical; tested): 0 = one wave per 8x8 tile,
  * 1 = persistent waves that pull tiles from per-XCD queues and refill finished lanes.  Process-wide. */
 int cgrt_set_primary_mode(int mode);
-/* Kernel shape of the certified walk, chosen per launch (no counterpart upstream; DESIGN.md "Latency shape"; results are
- * identical, tested): lane per ray is the throughput shape; quad per ray (four lanes test a node's four boxes, 16 rays per wave)
- * shortens the dependent chain of the hardest rays and is taken by launches of at most `max_rays` rays -- ray lists, and frames
- * or frame shares (cgrt_trace_primary* with nranks > 1) -- when mode = -1 (default); 0 = lane per ray always, 1 = quad per ray
- * whenever the scene has a fast tree.  max_rays = 0 keeps the current threshold.  Process-wide. */
+/* Kernel shape of the certified walk, chosen per launch (no counterpart upstream; DESIGN.md "Latency shapes"; results are
+ * identical, tested).  A launch ends when its hardest rays end, and a hard ray's dependent chain runs ~2x faster when it does not
+ * share its wave with 63 others, so SHORT RAY LISTS are laid out sparsely:
+ *   mode -1 (default) by size: lists of at most 8192 rays -> 4 rays per wave, 16 lanes per ray (four stack entries x four child
+ *            boxes per round); of at most max_rays (default 131072) -> one ray per lane, 16 rays per single-wave workgroup (the wave
+ *            is in the quad tail, four lanes per ray, from its first step); larger lists and every frame: 64 rays per wave.
+ *            Lists sized on the device (cgrt_render's wavefront) choose between 16 and 64 per wave on the device.
+ *   mode 0 = 64 rays per wave always (round 2's behaviour), 1 = quad per ray with 16 rays per wave (frames too), 2 = 16 rays per
+ *            wave for every list, 3 = 4 rays per wave for every list: for tests and measurements.
+ * max_rays = 0 keeps the current threshold.  Process-wide. */
 int cgrt_set_kernel_shape(int mode, uint64_t max_rays);
 int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays);
 /* Certified walk (no counterpart upstream; DESIGN.md "Certified walk").  The exact walk takes every step of the
@@ -152,6 +159,9 @@ uint64_t cgrt_device_bytes(const CgrtScene* scene);
  * normals (optional, n x 3) receives hitInfo.normal for rays that hit (left untouched otherwise, as
  * the reference leaves HitInfo untouched on a miss).  Host pointers; synchronous. */
 int cgrt_intersect_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, CgrtHit* hits, float* normals);
+/* Call combining for small cgrt_intersect_batch calls (see "Threads" above; DESIGN.md "Per-ray boundary"): 1 = on (default),
+ * 0 = every call launches for itself (round 2's behaviour).  Results are identical.  Process-wide. */
+int cgrt_set_call_combining(int enabled);
 /* intersectRayWithShape(const Mesh&, Ray&, HitInfo&) (ray_tracing.cpp:202-213) for n rays: every triangle is tested, no
  * tree -- the reference's ground truth over all triangles (its BVH misses hits this loop finds: SURVEY.md F4).
  *   mesh >= 0: that mesh only (index into the scene's meshes); material_id stays -1, the loop never writes hitInfo.material.
@@ -213,6 +223,12 @@ typedef struct CgrtSoftShadows {
 } CgrtSoftShadows;
 int cgrt_render_soft(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
                      const CgrtSoftShadows* soft, int max_level, float* rgb, CgrtRenderStats* stats);
+/* cgrt_render_soft without the last copy: *rgb receives a pointer to the frame in PINNED host memory owned by the scene (W*H*3
+ * floats, index y*W+x), into which the device frame was downloaded with one asynchronous copy; it stays valid until the next
+ * cgrt_render* call on this scene or cgrt_scene_destroy.  For callers that convert the frame anyway (Screen::setPixel's flip,
+ * screen.cpp:30-36): a 1920x1080 float frame is 25 MB, and copying it once more costs several device frames.  soft may be NULL. */
+int cgrt_render_mapped(CgrtScene* scene, const CgrtCamera* cam, int W, int H, const float* lights, uint32_t nlights,
+                       const CgrtSoftShadows* soft, int max_level, const float** rgb, CgrtRenderStats* stats);
 /* Image tiling across GPUs for whole frames: this call traces and shades only the pixels whose
  * 64x64 super-tile index % nranks == rank (the ownership rule of cgrt_trace_primary); every secondary ray of a pixel
  * stays on the GPU that owns the pixel, so ranks exchange nothing.  rgb of pixels owned by other ranks is left as the

@@ -1,8 +1,11 @@
-"""GPU parity tests of the QUAD-PER-RAY kernel shape (walk_quad.h): four lanes per ray, a node's four boxes in parallel, 16
-rays per wave, a row of 16 lanes per ray once <= 4 rays are live.  The shape changes only how the certified search is laid
-out on the lanes -- same tree, same arithmetic, same scan rule, same certificate, exact walk as fallback -- so every result must
-equal the lane-per-ray shape's, hence the oracle's, bit for bit: ray lists (closest hit + normals), occlusion lists inside
-cgrt_render, primary frames (plain, rank-tiled, packed multi-device order) and whole shaded frames."""
+"""GPU parity tests of the kernel SHAPES (trace_kernels.hip "kernel shape per launch"): how a launch lays its rays out on the lanes.
+  0 lane64  one ray per lane, 64 per wave (round 2's shape)         2 lane16  one ray per lane, 16 per single-wave workgroup
+  1 quad16  quad per ray, a node's four boxes in parallel (walk_quad.h), 16 rays per wave, 16 lanes per ray once <= 4 are live
+  3 quad4   4 rays per wave: 16 lanes per ray (4 stack entries x 4 boxes) from the first step
+The shape changes only the layout of the certified search -- same tree, same arithmetic, same scan rule, same certificate, exact
+walk as fallback -- so every result must equal lane64's, hence the oracle's, bit for bit: ray lists (closest hit + normals),
+occlusion lists inside cgrt_render (incl. the choice made on the device for lists sized there), primary frames (plain,
+rank-tiled, packed multi-device order) and whole shaded frames."""
 import numpy as np
 import pytest
 
@@ -15,11 +18,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def shapes(pkg):
-    """Calls fn under both shapes and returns (lane_per_ray, quad_per_ray)."""
+    """Calls fn under shapes 0 (lane64) and `others` (default: quad16) and returns the results in that order."""
 
-    def both(fn):
+    def both(fn, others=(1,)):
         out = []
-        for mode in (0, 1):
+        for mode in (0,) + tuple(others):
             pkg.set_kernel_shape(mode)
             try:
                 out.append(fn())
@@ -49,14 +52,26 @@ def test_quad_shape_ray_lists_equal_lane_shape_and_oracle(pkg, orc, shapes, ntri
     assert sc.walk() == 1
     for k in sorted(fam):
         r = _rays(pkg, fam[k])
-        (h0, n0), (h1, n1) = shapes(lambda: sc.intersect(r))
-        assert h0.tobytes() == h1.tobytes() and n0.tobytes() == n1.tobytes(), k
-        _assert_hits_equal(h1, n1, o.intersect(fam[k]), f"dragon{ntris}/{k} quad shape")
-    # list lengths that are not multiples of 16 (a wave's rays) or 4: partial waves, single rays
+        res = shapes(lambda: sc.intersect(r), others=(1, 2, 3))
+        for h, nn in res[1:]:
+            assert res[0][0].tobytes() == h.tobytes() and res[0][1].tobytes() == nn.tobytes(), k
+        _assert_hits_equal(res[1][0], res[1][1], o.intersect(fam[k]), f"dragon{ntris}/{k} quad shape")
+    # list lengths that are not multiples of 16 / 4 (a wave's rays): partial waves, single rays
     rays = _rays(pkg, rayfam.concat(fam))
-    for n in (1, 3, 15, 17, 63, 65, 1000):
-        (h0, n0), (h1, n1) = shapes(lambda: sc.intersect(rays[:n]))
-        assert h0.tobytes() == h1.tobytes() and n0.tobytes() == n1.tobytes(), n
+    for n in (1, 3, 5, 15, 17, 63, 65, 1000):
+        res = shapes(lambda: sc.intersect(rays[:n]), others=(1, 2, 3))
+        for h, nn in res[1:]:
+            assert res[0][0].tobytes() == h.tobytes() and res[0][1].tobytes() == nn.tobytes(), n
+    # the default policy (by size) on lists either side of its thresholds
+    pkg.set_kernel_shape(-1)
+    big = np.tile(rays, 1 + 140_000 // len(rays))
+    ref_h, ref_n = res[0][0], res[0][1]
+    for n in (8192, 8193, 131_072, 131_073):
+        h, nn = sc.intersect(big[:n])
+        pkg.set_kernel_shape(0)
+        h0, n0 = sc.intersect(big[:n])
+        pkg.set_kernel_shape(-1)
+        assert h.tobytes() == h0.tobytes() and nn.tobytes() == n0.tobytes(), n
     # the work the two shapes report: same rays enter the tree, same rays fall back; the wide tail steps speculatively, so
     # node visits may differ a little, never the answer
     c0, c1 = shapes(lambda: sc.count_batch(rays))
@@ -78,8 +93,10 @@ def test_quad_shape_on_thin_leaf_scenes(pkg, orc, scene_data, shapes, forced_fas
     sc = pkg.Scene(sd)
     assert sc.walk() == 1
     rays = rayfam.concat(fam)
-    (h0, n0), (h1, n1) = shapes(lambda: sc.intersect(_rays(pkg, rays)))
-    assert h0.tobytes() == h1.tobytes() and n0.tobytes() == n1.tobytes()
+    res = shapes(lambda: sc.intersect(_rays(pkg, rays)), others=(1, 2, 3))
+    (h0, n0), (h1, n1) = res[0], res[1]
+    for h, nn in res[1:]:
+        assert h0.tobytes() == h.tobytes() and n0.tobytes() == nn.tobytes()
     _assert_hits_equal(h1, n1, o.intersect(rays), f"{name} quad shape")
     c0, c1 = shapes(lambda: sc.count_batch(_rays(pkg, rays)))
     assert c0["fallback_rays"] == c1["fallback_rays"]
@@ -120,11 +137,13 @@ def test_quad_shape_shaded_frames(pkg, scene_data, shapes, forced_fast_tree, sce
     cam = pkg.scenes.default_camera(W, H)
     sc = pkg.Scene(sd)
     for depth in (1, 2, 4):
-        (rgb0, st0), (rgb1, st1) = shapes(lambda: sc.render(cam, W, H, max_level=depth))
-        assert rgb0.tobytes() == rgb1.tobytes(), depth
-        for k in ("primary_rays", "shadow_rays", "reflection_rays", "levels"):
-            assert st0[k] == st1[k], (k, depth)
-    assert np.count_nonzero(rgb1) > 0
+        res = shapes(lambda: sc.render(cam, W, H, max_level=depth), others=(1, 2, 3, -1))  # -1: the lists pick 16 / 64 per wave on the device
+        rgb0, st0 = res[0]
+        for rgb1, st1 in res[1:]:
+            assert rgb0.tobytes() == rgb1.tobytes(), depth
+            for k in ("primary_rays", "shadow_rays", "reflection_rays", "levels"):
+                assert st0[k] == st1[k], (k, depth)
+    assert np.count_nonzero(rgb0) > 0
 
 
 def test_kernel_shape_api(pkg):
@@ -135,5 +154,8 @@ def test_kernel_shape_api(pkg):
     pkg.set_kernel_shape(-1, 12345)
     assert pkg.kernel_shape() == (-1, 12345)
     pkg.set_kernel_shape(-1, max_rays)
+    for m in (0, 1, 2, 3, -1):
+        pkg.set_kernel_shape(m)
+        assert pkg.kernel_shape()[0] == m
     with pytest.raises(pkg.CgrtError):
         pkg.set_kernel_shape(7)

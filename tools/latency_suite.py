@@ -36,6 +36,7 @@ def ev_time(fn, k=K, warm=3):
 
 
 out = {"tag": tag}
+PARTS = os.environ.get("SUITE_PARTS", "frames,lists,shaded").split(",")
 buf = torch.empty(3840 * 2160 * 4, dtype=torch.int32, device="cuda")
 
 
@@ -44,12 +45,16 @@ def frame(W, H, rank=0, n=1):
     return ev_time(lambda: sc.trace_primary_device(cam, W, H, buf.data_ptr(), rank=rank, nranks=n))
 
 
-out["share8_us"] = [round(frame(3840, 2160, r, 8), 1) for r in range(8)]
-out["share8_max_us"] = max(out["share8_us"])
-out["share4_max_us"] = round(max(frame(3840, 2160, r, 4) for r in range(4)), 1)
-out["p2160_us"] = round(frame(3840, 2160), 1)
-out["p1080_us"] = round(frame(1920, 1080), 1)
-out["q540_us"] = round(frame(960, 540), 1)
+if "frames" in PARTS:
+    out["share8_us"] = [round(frame(3840, 2160, r, 8), 1) for r in range(8)]
+    out["share8_max_us"] = max(out["share8_us"])
+    out["share4_max_us"] = round(max(frame(3840, 2160, r, 4) for r in range(4)), 1)
+    out["p2160_us"] = round(frame(3840, 2160), 1)
+    out["p1080_us"] = round(frame(1920, 1080), 1)
+    out["q540_us"] = round(frame(960, 540), 1)
+if "lists" not in PARTS and "shaded" not in PARTS:
+    print(json.dumps(out), flush=True)
+    sys.exit(0)
 
 # the shaded frame's level-1 shadow list, rebuilt on the host (as tools/exp_secondary_lists.py)
 W, H = 1920, 1080
@@ -99,6 +104,11 @@ def list_time(r, k=K):
 
 
 sub = s1[:4096]
+if "lists" not in PARTS:
+    best = min(sc.render(cam, W, H, max_level=2)[1]["device_ms"] for _ in range(10))
+    out["shaded_ms"] = round(best, 4)
+    print(json.dumps(out), flush=True)
+    sys.exit(0)
 out["list4k_us"] = list_time(sub)
 out["list16k_us"] = list_time(s1[:16384])
 out["list64k_us"] = list_time(s1)
@@ -120,6 +130,7 @@ miss["origin"] = (10, 10, 10)
 miss["direction"] = (0, 0, 1)
 miss["t"] = np.finfo(np.float32).max
 out["miss4k_us"] = list_time(miss)
-best = min(sc.render(cam, W, H, max_level=2)[1]["device_ms"] for _ in range(10))
-out["shaded_ms"] = round(best, 4)
+if "shaded" in PARTS:
+    best = min(sc.render(cam, W, H, max_level=2)[1]["device_ms"] for _ in range(10))
+    out["shaded_ms"] = round(best, 4)
 print(json.dumps(out), flush=True)

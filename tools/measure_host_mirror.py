@@ -14,3 +14,7 @@ for on_device in (False, True, False, True):
     rgb, st = pkg.host_render_soft(sd, cam, W, H, none, None, max_level=2, on_device=on_device)
     print(f"on_device={on_device}: driver total {st['seconds_total'] * 1e3:.2f} ms, of which device/batch calls {st['seconds_device'] * 1e3:.2f} ms; "
           f"rays {st['primary'] + st['shadow'] + st['reflection']}", flush=True)
+t = pkg.host_time_screen_render(sd, cam, W, H, max_level=2, reps=5)
+print(f"Screen-filling drivers, whole call, BVH built once, best of 5: renderRayTracingOnDevice {t['on_device_ms']:.2f} ms "
+      f"(device share {t['on_device_device_share_ms']:.3f} ms; pinned frame -> Screen::setFrame), renderRayTracing (host-driven wavefront) "
+      f"{t['host_wavefront_ms']:.1f} ms")

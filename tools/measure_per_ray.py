@@ -1,0 +1,52 @@
+"""The UNCHANGED host at a usable speed?  Two measurements on the GPU box, printed for INTEGRATION.md:
+ 1. aggregate per-ray call rate -- T std::threads calling BoundingVolumeHierarchy::intersect(Ray&, HitInfo&) on ONE object through the
+    C++ mirror (cgrt_host_threads_test), call combining off (round 2: a launch per ray) and on, T = 1, 8, 64, 256;
+ 2. the reference's frame through its own structure taken literally (`render --per-ray`: omp parallel for over rows, per-pixel
+    recursive getFinalColor, one intersect call per ray): monkey 800x800 (windowResolution, main.cpp:29), depth 2, with T caller
+    threads -- beside the CPU oracle's time for the SAME frame (recursive per-pixel driver, all host cores, -O2 and -O0) and the
+    mirror's batched wavefront / device driver."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as e
+
+pkg = e.load_package()
+orc = e.load_oracle()
+sd = pkg.scenes.SceneData.load(os.path.join(e.ROOT, "tests", "golden", "scenes", "monkey.npz"))
+W = H = 800
+cam = pkg.scenes.default_camera(W, H)
+rays = orc.generate_rays(cam, W, H)
+print(f"host cores: {os.cpu_count()}; scene monkey-rotated.obj ({sd.ntris} triangles), {W}x{H}")
+for combining in (False, True):
+    pkg.set_call_combining(combining)
+    for T in (1, 8, 64, 256):
+        n = min(len(rays), 4000 * T if combining else 1500 * T)
+        bad, tim = pkg.host_threads_test(sd, rays[:n], nthreads=T)
+        print(f"call combining {'on ' if combining else 'off'} {T:4d} threads: {tim['calls_per_second']:10.0f} per-ray calls/s "
+              f"({tim['us_per_call_per_thread']:7.1f} us per call per thread; one thread alone {tim['us_per_call_one_thread']:.1f} us), disagreements {bad}", flush=True)
+pkg.set_call_combining(True)
+o2 = orc.OracleScene(sd)
+t0 = time.time()
+ref, nrays = o2.render(cam, W, H, sd.point_lights, max_level=2)
+t_o2 = time.time() - t0
+o0 = orc.OracleScene(sd, o0=True)
+t0 = time.time()
+o0.render(cam, W, H, sd.point_lights, max_level=2)
+t_o0 = time.time() - t0
+print(f"frame {W}x{H} depth 2 = {nrays} rays: CPU oracle (recursive per-pixel driver, {os.cpu_count()} threads) -O2 {t_o2 * 1e3:.0f} ms, -O0 {t_o0 * 1e3:.0f} ms "
+      f"(BASELINE.md: the report's monkey frame 0.5 s on unstated hardware)")
+for T in (8, 64, 256):
+    rgb, st = pkg.host_render_per_ray(sd, cam, W, H, 2, threads=T)
+    err = np.abs(rgb.astype(np.float64) - ref).max()
+    print(f"render --per-ray, {T:3d} caller threads: {st['seconds_total'] * 1e3:8.0f} ms ({nrays / st['seconds_total'] / 1e6:.2f} M per-ray calls/s), max |dRGB| vs oracle {err:.2e}", flush=True)
+pkg.set_call_combining(False)
+rgb, st = pkg.host_render_per_ray(sd, cam, W, H, 2, threads=8)
+print(f"render --per-ray,   8 caller threads, combining OFF (round 2's boundary): {st['seconds_total'] * 1e3:8.0f} ms")
+pkg.set_call_combining(True)
+rgb, st = pkg.host_render(sd, cam, W, H, 2)
+print(f"mirror's batched wavefront (renderRayTracing): {st['seconds_total'] * 1e3:.1f} ms")
+sc = pkg.Scene(sd)
+sc.render(cam, W, H, max_level=2)
+t0 = time.time()
+_, st = sc.render(cam, W, H, max_level=2)
+print(f"device driver (cgrt_render): {(time.time() - t0) * 1e3:.1f} ms whole call, {st['device_ms']:.3f} ms on the device")
