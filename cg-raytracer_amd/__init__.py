@@ -107,7 +107,7 @@ _lib: Optional[C.CDLL] = None
 # every symbol include/cgrt.h declares
 EXPORTS = [
     "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_kernel_shape", "cgrt_get_kernel_shape", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_scene_build_info", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
-    "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_set_call_combining", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
+    "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_set_call_combining", "cgrt_debug_combiner_stats", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
     "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_mapped", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_debug_layout_hash", "cgrt_set_build_threads", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
     "cgrt_triangle_plane_batch", "cgrt_point_in_triangle_batch", "cgrt_device_count", "cgrt_last_error", "cgrt_version", "cgrt_source_hash",
@@ -156,6 +156,7 @@ def lib() -> C.CDLL:
     L.cgrt_intersect_batch.argtypes = [vp, vp, u64, vp, vp]
     L.cgrt_intersect_brute_batch.argtypes = [vp, vp, u64, i32, vp, vp]
     L.cgrt_set_call_combining.argtypes = [i32]
+    L.cgrt_debug_combiner_stats.argtypes = [vp, vp]
     L.cgrt_intersect_batch_device.argtypes = [vp, vp, u64, vp, vp, vp]
     L.cgrt_trace_primary.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp]
     L.cgrt_trace_primary_device.argtypes = [vp, C.POINTER(Camera)] + [i32] * 8 + [vp, vp, vp]
@@ -710,11 +711,13 @@ def host_threads_test(sd: SceneData, rays7, nthreads: int = 8):
     pn, tri = _f32(sd.pos_nrm, (-1, 6)), np.ascontiguousarray(sd.tri, np.uint32).reshape(-1, 3)
     tm, mats = np.ascontiguousarray(sd.tri_mesh, np.uint32), _f32(sd.materials, (-1, 8))
     r = _f32(rays7, (-1, 7))
-    tim = np.zeros(3, np.float64)
+    tim = np.zeros(8, np.float64)
     bad = Hl.cgrt_host_threads_test(_ptr(pn), len(pn), _ptr(tri), _ptr(tm), len(tri), _ptr(mats), len(mats), _ptr(r), len(r), nthreads, _ptr(tim))
     if bad < 0:
         raise RuntimeError("cgrt_host_threads_test: " + Hl.cgrt_host_last_error().decode())
-    return int(bad), dict(us_per_call_one_thread=float(tim[0]), us_per_call_per_thread=float(tim[1]), calls_per_second=float(tim[2]))
+    return int(bad), dict(us_per_call_one_thread=float(tim[0]), us_per_call_per_thread=float(tim[1]), calls_per_second=float(tim[2]),
+                          combined_generations=int(tim[3]), combined_rays=int(tim[4]), largest_generation=int(tim[5]),
+                          leader_gpu_us_per_generation=float(tim[6]) / 1e3 / max(1.0, float(tim[3])))
 
 
 def host_render_bmp(sd: SceneData, cam, W: int, H: int, path: str, max_level: int = 2, nreplicas: int = 1):

@@ -185,22 +185,32 @@ struct CgrtScene {
     struct Combiner {
         static const uint32_t CAP = 4096;   // rays per generation
         static const uint32_t MAX_N = 64;   // calls with more rays than this take the direct path
-        enum State : int { FREE = 0, OPEN = 1, RUNNING = 2, DONE = 3 };
-        struct Ring {
+        enum State : uint64_t { FREE = 0, OPEN = 1, RUNNING = 2, DONE = 3 };
+        // One 64-bit word per ring says everything a caller needs, so joining, leader election and closing are single
+        // compare-and-swaps and nobody takes a lock on the way in (with a mutex 64 callers formed a convoy: 139 K calls/s):
+        //   bits 0..1 state | 2..15 callers that joined | 16..31 rays appended | 32..63 generation number
+        static uint64_t pack(uint64_t st, uint64_t joined, uint64_t count, uint64_t gen) { return st | (joined << 2) | (count << 16) | (gen << 32); }
+        static uint64_t st_of(uint64_t w) { return w & 3u; }
+        static uint32_t joined_of(uint64_t w) { return (uint32_t)((w >> 2) & 0x3fffu); }
+        static uint32_t count_of(uint64_t w) { return (uint32_t)((w >> 16) & 0xffffu); }
+        struct alignas(64) Ring {
+            std::atomic<uint64_t> word{0};     // FREE, generation 0
+            char pad0[56];
+            std::atomic<uint32_t> copied{0};   // joiners whose rays are in the ring (the leader launches when copied == joined)
+            std::atomic<uint32_t> readers{0};  // callers that still have to copy their results out (the last one frees the ring)
+            char pad1[56];
             void* host = nullptr;  // pinned + mapped: [CgrtRay x CAP | CgrtHit x CAP | normals 3 x CAP]
             void* dev = nullptr;   // the same memory as the device sees it
             hipStream_t stream = nullptr;
-            std::atomic<int> state{FREE};
-            uint32_t count = 0;        // rays appended (under mu)
-            uint32_t joined = 0;       // callers that appended (under mu)
-            std::atomic<uint32_t> readers_hint{0};  // = joined, readable without mu (the leader's grace period only)
-            std::atomic<uint32_t> readers{0};  // callers that still have to copy their results out
-            int rc = 0;                // the leader's status for the whole generation
+            int rc = 0;            // the leader's status for the whole generation (written before DONE is published)
             std::string err;
         } ring[2];
-        std::mutex mu;
+        std::mutex init_mu;
         std::atomic<int> inside{0};   // callers currently inside the combining entry (how many more may join a generation)
-        bool ready = false, failed = false;
+        std::atomic<int> ready{0};    // 0 = rings not allocated yet, 1 = usable, -1 = allocation failed (direct path for good)
+        // diagnostics (cgrt_debug_combiner_stats): generations launched, rays in them, the largest generation, nanoseconds the
+        // leaders spent from closing a generation to its results (launch + kernel + stream wait)
+        std::atomic<uint64_t> n_gen{0}, n_rays{0}, max_gen{0}, ns_gpu{0};
     } comb;
     std::mutex render_mutex;  // cgrt_render* share the workspace below: one frame per scene at a time
     unsigned persistent_blocks = 1024;  // 4 workgroups per CU
@@ -214,6 +224,13 @@ struct CgrtScene {
     // asynchronous copy at PCIe speed; cgrt_render_mapped hands this memory to the caller instead of copying it once more
     void* pin_frame = nullptr;
     size_t pin_frame_cap = 0;
+    // streams and events of cgrt_render* (created once per scene, guarded by render_mutex: creating and destroying a stream and
+    // five events per frame cost more host time than the Cornell frame's device time)
+    struct RenderAux {
+        hipStream_t s = nullptr, copy = nullptr;  // second traversal stream; read-backs that must not wait for queued kernels
+        hipEvent_t spawned = nullptr, traced = nullptr, e0 = nullptr, e1 = nullptr, primary_done = nullptr;
+        uint32_t* pin_counts = nullptr;  // 64 pinned bytes for counter read-backs
+    } raux;
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
@@ -221,6 +238,11 @@ struct CgrtScene {
         for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues})
             if (p) (void)hipFree(p);
         if (pin_frame) (void)hipHostFree(pin_frame);
+        for (hipEvent_t e : {raux.spawned, raux.traced, raux.e0, raux.e1, raux.primary_done})
+            if (e) (void)hipEventDestroy(e);
+        for (hipStream_t st : {raux.s, raux.copy})
+            if (st) (void)hipStreamDestroy(st);
+        if (raux.pin_counts) (void)hipHostFree(raux.pin_counts);
         for (auto& r : comb.ring) {
             if (r.host) (void)hipHostFree(r.host);
             if (r.stream) (void)hipStreamDestroy(r.stream);
@@ -746,8 +768,8 @@ int cgrt_intersect_batch_device(CgrtScene* s, const CgrtRay* d_rays, uint64_t n,
 }
 
 namespace {
-inline void cpu_relax(unsigned& spins) {
-    if (++spins < 64)
+inline void cpu_relax(unsigned& spins) {  // a wait of a few microseconds is the common case: spin first, then give the core away
+    if (++spins < 4096)
         __builtin_ia32_pause();
     else
         std::this_thread::yield();
@@ -757,80 +779,98 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
     typedef CgrtScene::Combiner C;
     C& cb = s->comb;
     const size_t off_hits = sizeof(CgrtRay) * C::CAP, off_nrm = off_hits + sizeof(CgrtHit) * C::CAP, total = off_nrm + 12 * (size_t)C::CAP;
+    int rdy = cb.ready.load(std::memory_order_acquire);
+    if (rdy == 0) {  // first call on this scene: the two rings
+        std::lock_guard<std::mutex> lk(cb.init_mu);
+        rdy = cb.ready.load(std::memory_order_acquire);
+        if (rdy == 0) {
+            bool ok = hipSetDevice(s->device) == hipSuccess;
+            for (auto& r : cb.ring) {
+                if (!ok) break;
+                hipError_t e = hipHostMalloc(&r.host, total, hipHostMallocMapped);
+                if (e == hipSuccess) e = hipHostGetDevicePointer(&r.dev, r.host, 0);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
+                ok = e == hipSuccess;  // (whatever was allocated is released with the scene)
+            }
+            rdy = ok ? 1 : -1;
+            cb.ready.store(rdy, std::memory_order_release);
+        }
+    }
+    if (rdy < 0) return 0;
     struct Inside {
         std::atomic<int>& c;
         explicit Inside(std::atomic<int>& x) : c(x) { c.fetch_add(1, std::memory_order_relaxed); }
         ~Inside() { c.fetch_sub(1, std::memory_order_relaxed); }
     } inside(cb.inside);
+    // ---- join the open generation, or open a free ring (and lead it) ----
     int b = -1;
     uint32_t at = 0;
+    uint64_t gen = 0;
     bool leader = false;
     unsigned spins = 0;
-    for (;;) {
-        {
-            std::lock_guard<std::mutex> lk(cb.mu);
-            if (cb.failed) return 0;
-            if (!cb.ready) {  // first call on this scene: the two rings
-                if (hipSetDevice(s->device) != hipSuccess) {
-                    cb.failed = true;
-                    return 0;
-                }
-                for (auto& r : cb.ring) {
-                    hipError_t e = hipHostMalloc(&r.host, total, hipHostMallocMapped);
-                    if (e == hipSuccess) e = hipHostGetDevicePointer(&r.dev, r.host, 0);
-                    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
-                    if (e != hipSuccess) {
-                        cb.failed = true;  // (whatever was allocated is released with the scene)
-                        return 0;
-                    }
-                }
-                cb.ready = true;
-            }
-            // join the open generation, or open a free ring
-            for (int k = 0; k < 2 && b < 0; k++) {
-                C::Ring& r = cb.ring[k];
-                if (r.state.load(std::memory_order_acquire) == C::OPEN && r.count + n <= C::CAP) b = k;
-            }
-            for (int k = 0; k < 2 && b < 0; k++) {
-                C::Ring& r = cb.ring[k];
-                if (r.state.load(std::memory_order_acquire) == C::FREE) {
-                    r.count = 0;
-                    r.joined = 0;
-                    r.readers_hint.store(0, std::memory_order_relaxed);
-                    r.rc = 0;
-                    r.state.store(C::OPEN, std::memory_order_release);
-                    leader = true;
+    while (b < 0) {
+        for (int k = 0; k < 2 && b < 0; k++) {
+            C::Ring& r = cb.ring[k];
+            uint64_t w = r.word.load(std::memory_order_acquire);
+            while (C::st_of(w) == C::OPEN && C::count_of(w) + n <= C::CAP) {
+                const uint64_t nw = C::pack(C::OPEN, C::joined_of(w) + 1u, C::count_of(w) + n, w >> 32);
+                if (r.word.compare_exchange_weak(w, nw, std::memory_order_acq_rel, std::memory_order_acquire)) {
                     b = k;
+                    at = C::count_of(w);
+                    gen = w >> 32;
+                    break;
                 }
-            }
-            if (b >= 0) {
-                C::Ring& r = cb.ring[b];
-                at = r.count;
-                r.count += n;
-                r.joined += 1;
-                r.readers_hint.store(r.joined, std::memory_order_relaxed);
-                std::memcpy(static_cast<char*>(r.host) + sizeof(CgrtRay) * (size_t)at, rays, sizeof(CgrtRay) * (size_t)n);
-                break;
             }
         }
-        cpu_relax(spins);  // both rings are on the GPU or being read out: the next generation opens in a moment
+        for (int k = 0; k < 2 && b < 0; k++) {
+            C::Ring& r = cb.ring[k];
+            uint64_t w = r.word.load(std::memory_order_acquire);
+            if (C::st_of(w) != C::FREE) continue;
+            // (copied == 0 and readers == 0 here: the last reader of the previous generation reset them before it freed the ring)
+            const uint64_t nw = C::pack(C::OPEN, 1u, n, w >> 32);
+            if (r.word.compare_exchange_strong(w, nw, std::memory_order_acq_rel, std::memory_order_acquire)) {
+                b = k;
+                at = 0;
+                gen = w >> 32;
+                leader = true;
+            }
+        }
+        if (b < 0) cpu_relax(spins);  // both rings are on the GPU or being read out: the next generation opens in a moment
     }
     C::Ring& r = cb.ring[b];
+    std::memcpy(static_cast<char*>(r.host) + sizeof(CgrtRay) * (size_t)at, rays, sizeof(CgrtRay) * (size_t)n);
+    r.copied.fetch_add(1, std::memory_order_release);
     if (leader) {
-        // a short grace period while other callers are on their way in (they are already past the entry): a few hundred ns
-        // (callers parked on the other ring count as in: they are not coming)
-        for (unsigned k = 0; k < 200; k++) {
-            const C::Ring& o = cb.ring[b ^ 1];
-            const int parked = (o.state.load(std::memory_order_relaxed) != C::FREE) ? (int)o.readers_hint.load(std::memory_order_relaxed) : 0;
-            if ((int)r.readers_hint.load(std::memory_order_relaxed) + parked >= cb.inside.load(std::memory_order_relaxed)) break;
+        // a short grace period while other callers are on their way in (callers parked on the other ring are not coming)
+        // -- until everybody inside the entry has joined, or nobody new has for a moment; a few microseconds at most
+        uint32_t last = 0, quiet = 0;
+        for (unsigned k = 0; k < 1000; k++) {
+            const uint64_t ow = cb.ring[b ^ 1].word.load(std::memory_order_relaxed);
+            const int parked = (C::st_of(ow) == C::RUNNING || C::st_of(ow) == C::DONE) ? (int)cb.ring[b ^ 1].readers.load(std::memory_order_relaxed) : 0;
+            const uint32_t j = C::joined_of(r.word.load(std::memory_order_relaxed));
+            if ((int)j + parked >= cb.inside.load(std::memory_order_relaxed)) break;
+            if (j != last) {
+                last = j;
+                quiet = 0;
+            } else if (++quiet > 100) {
+                break;
+            }
             __builtin_ia32_pause();
         }
-        uint32_t cnt;
-        {
-            std::lock_guard<std::mutex> lk(cb.mu);
-            r.state.store(C::RUNNING, std::memory_order_release);  // closed: later callers open the other ring
-            cnt = r.count;
+        // close: OPEN -> RUNNING fixes the number of rays and of joiners in one step
+        uint64_t w = r.word.load(std::memory_order_acquire);
+        while (!r.word.compare_exchange_weak(w, C::pack(C::RUNNING, C::joined_of(w), C::count_of(w), w >> 32), std::memory_order_acq_rel,
+                                            std::memory_order_acquire)) {
         }
+        const uint32_t cnt = C::count_of(w), joined = C::joined_of(w);
+        r.readers.store(joined, std::memory_order_relaxed);
+        const auto t_closed = std::chrono::steady_clock::now();
+        cb.n_gen.fetch_add(1, std::memory_order_relaxed);
+        cb.n_rays.fetch_add(cnt, std::memory_order_relaxed);
+        for (uint64_t m = cb.max_gen.load(std::memory_order_relaxed); m < cnt && !cb.max_gen.compare_exchange_weak(m, cnt, std::memory_order_relaxed);) {
+        }
+        unsigned sp = 0;
+        while (r.copied.load(std::memory_order_acquire) != joined) cpu_relax(sp);  // every joiner's rays are in the ring
         int rc = CGRT_OK;
         hipError_t e = hipSetDevice(s->device);
         if (e == hipSuccess)
@@ -842,11 +882,16 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
             r.err = std::string("combined launch: ") + hipGetErrorString(e);
         }
         r.rc = rc;
-        r.readers.store(r.joined, std::memory_order_relaxed);  // (joined is final: the generation was closed under mu)
-        r.state.store(C::DONE, std::memory_order_release);
+        cb.ns_gpu.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_closed).count(),
+                            std::memory_order_relaxed);
+        r.word.store(C::pack(C::DONE, joined, cnt, gen), std::memory_order_release);
     } else {
         unsigned sp = 0;
-        while (r.state.load(std::memory_order_acquire) != C::DONE) cpu_relax(sp);
+        for (;;) {
+            const uint64_t w = r.word.load(std::memory_order_acquire);
+            if (C::st_of(w) == C::DONE && (w >> 32) == gen) break;
+            cpu_relax(sp);
+        }
     }
     rc_out = r.rc;
     if (r.rc == CGRT_OK) {
@@ -859,11 +904,22 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
     } else {
         g_err = r.err;
     }
-    if (r.readers.fetch_sub(1, std::memory_order_acq_rel) == 1) r.state.store(C::FREE, std::memory_order_release);  // last one out
+    if (r.readers.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // last one out: the ring is free for generation gen + 1
+        r.copied.store(0, std::memory_order_relaxed);
+        r.word.store(C::pack(C::FREE, 0, 0, (gen + 1) & 0xffffffffull), std::memory_order_release);
+    }
     return 1;
 }
 }  // namespace
 
+int cgrt_debug_combiner_stats(const CgrtScene* s, uint64_t* out4) {
+    if (!s || !out4) return fail(CGRT_E_ARG, "NULL argument");
+    out4[0] = s->comb.n_gen.load();
+    out4[1] = s->comb.n_rays.load();
+    out4[2] = s->comb.max_gen.load();
+    out4[3] = s->comb.ns_gpu.load();
+    return CGRT_OK;
+}
 int cgrt_set_call_combining(int enabled) {
     g_call_combining.store(enabled ? 1 : 0);
     return CGRT_OK;
@@ -1179,22 +1235,17 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         Q.seed = soft->seed;
     }
     const CameraDev C = make_camera(*cam);
-    struct Aux {  // second stream + the events that order it against the default stream
-        hipStream_t s = nullptr;
-        hipEvent_t spawned = nullptr, traced = nullptr, e0 = nullptr, e1 = nullptr;
-        ~Aux() {
-            if (spawned) (void)hipEventDestroy(spawned);
-            if (traced) (void)hipEventDestroy(traced);
-            if (e0) (void)hipEventDestroy(e0);
-            if (e1) (void)hipEventDestroy(e1);
-            if (s) (void)hipStreamDestroy(s);
-        }
-    } aux;
-    HIP_TRY(hipStreamCreateWithFlags(&aux.s, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&aux.spawned, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&aux.traced, hipEventDisableTiming));
-    HIP_TRY(hipEventCreate(&aux.e0));
-    HIP_TRY(hipEventCreate(&aux.e1));
+    CgrtScene::RenderAux& aux = s->raux;  // second stream + the events that order it against the default stream
+    if (!aux.pin_counts) {
+        HIP_TRY(hipStreamCreateWithFlags(&aux.s, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&aux.copy, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&aux.spawned, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&aux.traced, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&aux.primary_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&aux.e0));
+        HIP_TRY(hipEventCreate(&aux.e1));
+        HIP_TRY(hipHostMalloc((void**)&aux.pin_counts, 64, hipHostMallocDefault));
+    }
     HIP_TRY(hipEventRecord(aux.e0, nullptr));
     int nlev = 0;
     bool finished = false;  // the frame's last kernels and its closing event have been issued inside the level loop
@@ -1207,10 +1258,19 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(),
                                              ipix.as<int>(), primary_hits, nullptr, cw_primary, drgb.as<float>()));  // (also clears this rank's pixels)
         st.primary_rays = owned_pixels(F);
-        uint32_t nhit0 = 0;
-        HIP_TRY(hipMemcpy(&nhit0, primary_hits, sizeof(nhit0), hipMemcpyDeviceToHost));
-        unsigned long long cnt = nhit0;
         const float* const mats = static_cast<const float*>(s->d_materials);
+        // Level 0's spawn does not wait for the host to learn how many primary rays hit: it is launched over every item of the
+        // rank's frame and stops at the count it reads on the device, while the host fetches that count on a stream of its own
+        // (behind the primary kernel only) to size the traversal launches that follow -- the host round trip (~25 us of an idle
+        // GPU per frame, profiles/r3_config3_timeline.txt) now overlaps the spawn kernel.
+        HIP_TRY(hipEventRecord(aux.primary_done, nullptr));
+        HIP_TRY(launch_spawn(rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), ipix.as<int>(), n, mats, dlights.as<float>(), L,
+                             1 < max_level, srays[0].as<float>(), sdist[0].as<float>(), sslot[0].as<int>(), levels.as<float>(), rays[1].as<float>(),
+                             pix[1].as<int>(), dctr.as<uint32_t>(), nullptr, primary_hits));
+        HIP_TRY(hipStreamWaitEvent(aux.copy, aux.primary_done, 0));
+        HIP_TRY(hipMemcpyAsync(aux.pin_counts, primary_hits, sizeof(uint32_t), hipMemcpyDeviceToHost, aux.copy));
+        HIP_TRY(hipStreamSynchronize(aux.copy));
+        unsigned long long cnt = aux.pin_counts[0];
         int level = 0;
         while (level < max_level && cnt > 0) {
             const int a = level % 3, b = (level + 1) % 3, q = level & 1;  // this level's buffer set, the next level's, this level's shadow set
@@ -1218,9 +1278,10 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             const int* cur_pix = level == 0 ? ipix.as<int>() : pix[a].as<int>();
             uint32_t* ctr = dctr.as<uint32_t>() + 4 * (size_t)level;
             float* lvl = levels.as<float>() + (size_t)level * n * 8;
-            HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), cur_pix, cnt, mats, dlights.as<float>(), L,
-                                 spawn, srays[q].as<float>(), sdist[q].as<float>(), sslot[q].as<int>(), lvl, rays[b].as<float>(), pix[b].as<int>(),
-                                 ctr, nullptr));
+            if (level > 0)  // (level 0's spawn is already in flight, see above)
+                HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), cur_pix, cnt, mats, dlights.as<float>(), L,
+                                     spawn, srays[q].as<float>(), sdist[q].as<float>(), sslot[q].as<int>(), lvl, rays[b].as<float>(), pix[b].as<int>(),
+                                     ctr, nullptr));
             // Level 0's mirror batch runs on the second stream, beside level 0's shadow batch (two batches of a few hundred
             // thousand rays each; its grid covers the list's capacity -- one mirror ray per entry -- and the kernel stops at the
             // appended count).  Without spherical lights the whole of level 1 follows it there -- spawn, shadow list, shading,

@@ -127,7 +127,11 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
         normals[3 * idx] = nn.x;
         normals[3 * idx + 1] = nn.y;
         normals[3 * idx + 2] = nn.z;
-        pixels[idx] = y * F.W + x;
+        int px = 0, py = 0;  // (the pixel is rebuilt rather than kept in registers through the walk)
+        size_t pi;
+        bool wr;
+        (void)frame_pixel<QUAD>(F, px, py, pi, wr);
+        pixels[idx] = py * F.W + px;
     }
 }
 // rgb of every pixel this rank owns := 0 (main.cpp:293; the hits are written over it afterwards)
@@ -173,7 +177,12 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
         walk_tree_quad<COUNT>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), cnt);
     else
         walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
-    if (active && writer) finish_ray(S, o, d, t, hit_rec, hits + i, normals ? normals + 3 * i : nullptr);
+    if (active && writer) {
+        // (the ray's index is rebuilt rather than kept in two registers through the walk)
+        const unsigned long long k = QUAD ? ((unsigned long long)blockIdx.x * qrpw + (threadIdx.x >> 2))
+                                          : (sparse ? (unsigned long long)blockIdx.x * qrpw + threadIdx.x : (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x);
+        finish_ray(S, o, d, t, hit_rec, hits + k, normals ? normals + 3 * k : nullptr);
+    }
     if (COUNT) flush_counters(cnt, active && writer, counters);
 }
 

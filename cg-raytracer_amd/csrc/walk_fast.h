@@ -222,17 +222,25 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
         float lt = G.best_t;
         uint32_t lr = G.best_rec;
         bool ltie = G.tie, lonp = false;
-        if (has && !(ref & REF_LEAF)) {  // a 4-wide node: its four boxes, hit children sorted near to far
+        // ONE round trip to memory per round: a node entry and a run entry are both "the 128 bytes this reference names" (a
+        // 4-wide node; the two records of a run, the first one twice for a run of one), so every lane requests its eight
+        // quarters before either kind is evaluated -- a quad whose entries are of both kinds no longer pays the latency twice
+        // (profiles/r3_exp_unified_tail.txt).
+        const bool is_node = has && !(ref & REF_LEAF), is_run = has && (ref & REF_LEAF) != 0u;
+        const uint32_t rfirst = run_first(ref), rcount = is_run ? run_count(ref) : 0u;
+        if (has) {
+        const float4* g = is_node ? reinterpret_cast<const float4*>(S.subnodes + ref) : reinterpret_cast<const float4*>(S.tris + rfirst);
+        const uint32_t j = (is_node || rcount > 1u) ? 4u : 0u;
+        const float4 u0 = g[0], u1 = g[1], u2 = g[2], u3 = g[3];
+        const float4 u4 = g[j], u5 = g[j + 1], u6 = g[j + 2], u7 = g[j + 3];
+        if (is_node) {  // a 4-wide node: its four boxes, hit children sorted near to far
             if (COUNT) {
                 cnt.sub++;
                 if (first_active_lane()) cnt.w_sub++;
             }
-            const float4* g = reinterpret_cast<const float4*>(S.subnodes + ref);
-            const float4 a0 = g[0], b0 = g[1], c0 = g[2];
-            const uint4 m = *reinterpret_cast<const uint4*>(g + 3);
-            const float4 a1 = g[4], b1 = g[5], c1 = g[6];
+            const uint4 m = make_uint4(__float_as_uint(u3.x), __float_as_uint(u3.y), __float_as_uint(u3.z), __float_as_uint(u3.w));
             float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
-            slab_cons4(P, a0, b0, c0, a1, b1, c1, tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3);
+            slab_cons4(P, u0, u1, u2, u4, u5, u6, tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3);
             const float tc = fmaxf(G.best_t, 0.0f);
             float k0 = ((tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= tc)) ? tn0 : inf;
             float k1 = ((tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= tc)) ? tn1 : inf;
@@ -256,18 +264,30 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
             CGRT_CSWAP(k1, r1, k2, r2)
 #undef CGRT_CSWAP
             c = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);  // hit children are r0 .. r(c-1)
-        }
-        if (has && (ref & REF_LEAF)) {  // a run of records
+        } else {  // a run of records: the first two are in the registers already
             FastScan L;
             L.best_t = G.best_t;
             L.best_rec = G.best_rec;
             L.tie = G.tie;
             L.onp = false;
-            fast_test_run<COUNT, MODE>(S, run_first(ref), run_count(ref), o, d, qlen, L, cnt);
+            if (COUNT) {
+                cnt.tri += rcount;
+                if (first_active_lane()) cnt.w_tri++;
+            }
+            TriEval E0, E1;
+            eval_pair(u0, u1, u2, u3, u4, u5, u6, u7, o, d, E0, E1);
+            fast_apply<MODE>(E0, rfirst, qlen, L);
+            if (rcount > 1u) fast_apply<MODE>(E1, rfirst + 1u, qlen, L);
+            if (rcount > 2u) {  // small leaves without accelerator (<= 32 records): the rest one by one
+                const float4* g = reinterpret_cast<const float4*>(S.tris + rfirst);
+                for (uint32_t i = 2; i < rcount; i++)
+                    fast_apply<MODE>(eval_record(g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], o, d), rfirst + i, qlen, L);
+            }
             lt = L.best_t;
             lr = L.best_rec;
             ltie = L.tie;
             lonp = L.onp;
+        }
         }
         // survivors back on the stack: lane 0 held the top entry, so its children go on top (pushed last), and inside a
         // lane the nearest child last
@@ -340,13 +360,73 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
             break;
         }
         if (!done) {
-            if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
-            if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
-            if (cur != REF_NONE && (cur & REF_LEAF)) {
-                fast_test_run<COUNT, MODE>(S, run_first(cur), run_count(cur), o, d, qlen, F, cnt);
-                cur = REF_NONE;
-                if (MODE != WALK_CLOSEST && (F.best_rec != REF_NONE || F.onp)) done = true;
-            }
+#ifndef CGRT_LOOP_NU
+#define CGRT_LOOP_NU 0  // trip shape (experiment): 0 = [node][node][run]; 1 = [node][U]; 2 = [U][U]; 3 = [node][node][U], where U = a node-or-run
+                        // step with ONE load phase (the 128 bytes the reference names are requested before either kind is evaluated)
+#endif
+            auto NODE = [&]() __attribute__((always_inline)) {
+                if (cur != REF_NONE && !(cur & REF_LEAF)) sub_node_step<COUNT>(S, W.P, F.best_t, cur, sp, stk, cnt);
+            };
+            auto RUN = [&]() __attribute__((always_inline)) {
+                if (cur != REF_NONE && (cur & REF_LEAF)) {
+                    fast_test_run<COUNT, MODE>(S, run_first(cur), run_count(cur), o, d, qlen, F, cnt);
+                    cur = REF_NONE;
+                    if (MODE != WALK_CLOSEST && (F.best_rec != REF_NONE || F.onp)) done = true;
+                }
+            };
+            auto UNI = [&]() __attribute__((always_inline)) {
+                if (cur != REF_NONE && !done) {
+                    const bool is_node = !(cur & REF_LEAF);
+                    const uint32_t rfirst = run_first(cur), rcount = is_node ? 0u : run_count(cur);
+                    const float4* g = is_node ? reinterpret_cast<const float4*>(S.subnodes + cur) : reinterpret_cast<const float4*>(S.tris + rfirst);
+                    const uint32_t j = (is_node || rcount > 1u) ? 4u : 0u;
+                    const float4 u0 = g[0], u1 = g[1], u2 = g[2], u3 = g[3];
+                    const float4 u4 = g[j], u5 = g[j + 1], u6 = g[j + 2], u7 = g[j + 3];
+                    if (is_node) {
+                        const uint4 m = make_uint4(__float_as_uint(u3.x), __float_as_uint(u3.y), __float_as_uint(u3.z), __float_as_uint(u3.w));
+                        sub_node_compute<COUNT>(W.P, F.best_t, u0, u1, u2, m, u4, u5, u6, cur, sp, stk, cnt);
+                    } else {
+                        if (COUNT) {
+                            cnt.tri += rcount;
+                            if (first_active_lane()) cnt.w_tri++;
+                        }
+                        TriEval E0, E1;
+                        eval_pair(u0, u1, u2, u3, u4, u5, u6, u7, o, d, E0, E1);
+                        fast_apply<MODE>(E0, rfirst, qlen, F);
+                        if (rcount > 1u) fast_apply<MODE>(E1, rfirst + 1u, qlen, F);
+                        for (uint32_t i = 2; i < rcount; i++)
+                            fast_apply<MODE>(eval_record(g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], o, d), rfirst + i, qlen, F);
+                        cur = REF_NONE;
+                        if (MODE != WALK_CLOSEST && (F.best_rec != REF_NONE || F.onp)) done = true;
+                    }
+                }
+            };
+            auto POP = [&]() __attribute__((always_inline)) {
+                if (cur == REF_NONE && !done && sp > 0) {
+                    sp -= 1;
+                    cur = stk[sp * CGRT_STRIDE];
+                }
+            };
+            (void)NODE;
+            (void)RUN;
+            (void)UNI;
+            (void)POP;
+#if CGRT_LOOP_NU == 1
+            NODE();
+            UNI();
+#elif CGRT_LOOP_NU == 2
+            UNI();
+            POP();
+            UNI();
+#elif CGRT_LOOP_NU == 3
+            NODE();
+            NODE();
+            UNI();
+#else
+            NODE();
+            NODE();
+            RUN();
+#endif
             if (cur == REF_NONE && !done) {
                 if (sp > 0) {
                     sp -= 1;

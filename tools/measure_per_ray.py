@@ -23,7 +23,9 @@ for combining in (False, True):
         n = min(len(rays), 4000 * T if combining else 1500 * T)
         bad, tim = pkg.host_threads_test(sd, rays[:n], nthreads=T)
         print(f"call combining {'on ' if combining else 'off'} {T:4d} threads: {tim['calls_per_second']:10.0f} per-ray calls/s "
-              f"({tim['us_per_call_per_thread']:7.1f} us per call per thread; one thread alone {tim['us_per_call_one_thread']:.1f} us), disagreements {bad}", flush=True)
+              f"({tim['us_per_call_per_thread']:7.1f} us per call per thread; one thread alone {tim['us_per_call_one_thread']:.1f} us), disagreements {bad}"
+              + (f"; {tim['combined_rays'] / max(1, tim['combined_generations']):.1f} rays per launch on average (largest {tim['largest_generation']}), "
+                 f"{tim['leader_gpu_us_per_generation']:.1f} us launch + kernel + wait per launch" if combining else ""), flush=True)
 pkg.set_call_combining(True)
 o2 = orc.OracleScene(sd)
 t0 = time.time()
