@@ -199,7 +199,13 @@ def main():
     setup_s = time.time() - t0
     if args.walk != "auto":
         scene.set_walk(args.walk == "certified")
+    if os.environ.get("CGRT_PRIMARY_MODE") == "1":
+        # the persistent-waves variant (variant_kernels.hip) walks exactly, whatever the scene carries: the line, its counters and
+        # its traffic key must describe what was launched
+        scene.set_walk(False)
     walk = "certified (fast tree + certificate, exact fallback)" if scene.walk() else "exact"
+    if os.environ.get("CGRT_PRIMARY_MODE") == "1":
+        walk += ", persistent waves with lane refill (cgrt_set_primary_mode(1))"
 
     main_stream = torch.cuda.current_stream()
 

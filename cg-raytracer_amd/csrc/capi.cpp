@@ -182,13 +182,23 @@ struct CgrtScene {
     // (the kernel reads the rays from and writes the hits to host memory directly: no copy commands), waits for that stream and
     // publishes the results; the other callers wait on the generation's state and copy their own hits out.  While a generation
     // is on the GPU the next one fills up, so the batch size adapts to the load.  Nothing stays resident on the device.
+#ifndef CGRT_COMBINE_RINGS
+#define CGRT_COMBINE_RINGS 2  // generations that can be open / in flight at a time (4 measured no better: profiles/r3_per_ray.txt)
+#endif
     struct Combiner {
-        static const uint32_t CAP = 4096;   // rays per generation
-        static const uint32_t MAX_N = 64;   // calls with more rays than this take the direct path
+        static const int NRINGS = CGRT_COMBINE_RINGS;
+        static const uint32_t CAP = 32768;       // ray slots per ring
+        static const uint32_t MAX_N = 64;        // calls with more rays than this take the direct path
+        static const int MAX_CALLERS = 256;      // callers inside the entry at a time (more take the direct path)
+        static const uint32_t JOIN_MAX = CAP - MAX_N * MAX_CALLERS;  // a generation is joined while it holds at most this many rays:
+                                                                     // MAX_CALLERS joins of MAX_N rays in flight cannot overflow it
         enum State : uint64_t { FREE = 0, OPEN = 1, RUNNING = 2, DONE = 3 };
-        // One 64-bit word per ring says everything a caller needs, so joining, leader election and closing are single
-        // compare-and-swaps and nobody takes a lock on the way in (with a mutex 64 callers formed a convoy: 139 K calls/s):
+        // One 64-bit word per ring says everything a caller needs, so joining is ONE atomic add, leader election and closing single
+        // compare-and-swaps, and nobody takes a lock on the way in (with a mutex 64 callers formed a convoy: 139 K calls/s):
         //   bits 0..1 state | 2..15 callers that joined | 16..31 rays appended | 32..63 generation number
+        // An add that arrives after the generation was closed lands on a RUNNING / DONE / FREE word: the adder sees the old state in
+        // the value it gets back and tries again elsewhere; the stray counts are overwritten by the next transition (the leader
+        // keeps its own copy of the counts it closed with), and the caller limit keeps them inside their bit fields.
         static uint64_t pack(uint64_t st, uint64_t joined, uint64_t count, uint64_t gen) { return st | (joined << 2) | (count << 16) | (gen << 32); }
         static uint64_t st_of(uint64_t w) { return w & 3u; }
         static uint32_t joined_of(uint64_t w) { return (uint32_t)((w >> 2) & 0x3fffu); }
@@ -196,18 +206,22 @@ struct CgrtScene {
         struct alignas(64) Ring {
             std::atomic<uint64_t> word{0};     // FREE, generation 0
             char pad0[56];
+            // what the WAITERS of a generation spin on -- a line of its own, written once per generation: spinning on `word`
+            // made every join fight 60 readers for the line (64 callers: 0.46 M calls/s)
+            std::atomic<uint32_t> done_gen{0}; // generations of this ring whose results are published
+            char pad1[60];
             std::atomic<uint32_t> copied{0};   // joiners whose rays are in the ring (the leader launches when copied == joined)
             std::atomic<uint32_t> readers{0};  // callers that still have to copy their results out (the last one frees the ring)
-            char pad1[56];
+            char pad2[56];
             void* host = nullptr;  // pinned + mapped: [CgrtRay x CAP | CgrtHit x CAP | normals 3 x CAP]
             void* dev = nullptr;   // the same memory as the device sees it
             hipStream_t stream = nullptr;
-            int rc = 0;            // the leader's status for the whole generation (written before DONE is published)
+            int rc = 0;            // the leader's status for the whole generation (written before done_gen is published)
             std::string err;
-        } ring[2];
+        } ring[CGRT_COMBINE_RINGS];
         std::mutex init_mu;
-        std::atomic<int> inside{0};   // callers currently inside the combining entry (how many more may join a generation)
-        std::atomic<int> ready{0};    // 0 = rings not allocated yet, 1 = usable, -1 = allocation failed (direct path for good)
+        alignas(64) std::atomic<int> inside{0};   // callers currently inside the combining entry
+        alignas(64) std::atomic<int> ready{0};    // 0 = rings not allocated yet, 1 = usable, -1 = allocation failed (direct path for good)
         // diagnostics (cgrt_debug_combiner_stats): generations launched, rays in them, the largest generation, nanoseconds the
         // leaders spent from closing a generation to its results (launch + kernel + stream wait)
         std::atomic<uint64_t> n_gen{0}, n_rays{0}, max_gen{0}, ns_gpu{0};
@@ -799,39 +813,38 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
     if (rdy < 0) return 0;
     struct Inside {
         std::atomic<int>& c;
-        explicit Inside(std::atomic<int>& x) : c(x) { c.fetch_add(1, std::memory_order_relaxed); }
+        int before;
+        explicit Inside(std::atomic<int>& x) : c(x), before(c.fetch_add(1, std::memory_order_relaxed)) {}
         ~Inside() { c.fetch_sub(1, std::memory_order_relaxed); }
     } inside(cb.inside);
+    if (inside.before >= C::MAX_CALLERS) return 0;  // (the bound the word's bit fields and JOIN_MAX rely on)
     // ---- join the open generation, or open a free ring (and lead it) ----
     int b = -1;
     uint32_t at = 0;
-    uint64_t gen = 0;
+    uint32_t gen = 0;
     bool leader = false;
     unsigned spins = 0;
     while (b < 0) {
-        for (int k = 0; k < 2 && b < 0; k++) {
+        for (int k = 0; k < C::NRINGS && b < 0; k++) {
             C::Ring& r = cb.ring[k];
-            uint64_t w = r.word.load(std::memory_order_acquire);
-            while (C::st_of(w) == C::OPEN && C::count_of(w) + n <= C::CAP) {
-                const uint64_t nw = C::pack(C::OPEN, C::joined_of(w) + 1u, C::count_of(w) + n, w >> 32);
-                if (r.word.compare_exchange_weak(w, nw, std::memory_order_acq_rel, std::memory_order_acquire)) {
-                    b = k;
-                    at = C::count_of(w);
-                    gen = w >> 32;
-                    break;
-                }
-            }
+            const uint64_t seen = r.word.load(std::memory_order_acquire);
+            if (C::st_of(seen) != C::OPEN || C::count_of(seen) > C::JOIN_MAX) continue;
+            const uint64_t w = r.word.fetch_add(((uint64_t)1 << 2) | ((uint64_t)n << 16), std::memory_order_acq_rel);
+            if (C::st_of(w) == C::OPEN) {  // joined: the slots [count, count + n) are this caller's
+                b = k;
+                at = C::count_of(w);
+                gen = (uint32_t)(w >> 32);
+            }  // else: closed in between -- the stray counts are harmless (see Combiner)
         }
-        for (int k = 0; k < 2 && b < 0; k++) {
+        for (int k = 0; k < C::NRINGS && b < 0; k++) {
             C::Ring& r = cb.ring[k];
             uint64_t w = r.word.load(std::memory_order_acquire);
             if (C::st_of(w) != C::FREE) continue;
             // (copied == 0 and readers == 0 here: the last reader of the previous generation reset them before it freed the ring)
-            const uint64_t nw = C::pack(C::OPEN, 1u, n, w >> 32);
-            if (r.word.compare_exchange_strong(w, nw, std::memory_order_acq_rel, std::memory_order_acquire)) {
+            if (r.word.compare_exchange_strong(w, C::pack(C::OPEN, 1u, n, w >> 32), std::memory_order_acq_rel, std::memory_order_acquire)) {
                 b = k;
                 at = 0;
-                gen = w >> 32;
+                gen = (uint32_t)(w >> 32);
                 leader = true;
             }
         }
@@ -845,8 +858,12 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         // -- until everybody inside the entry has joined, or nobody new has for a moment; a few microseconds at most
         uint32_t last = 0, quiet = 0;
         for (unsigned k = 0; k < 1000; k++) {
-            const uint64_t ow = cb.ring[b ^ 1].word.load(std::memory_order_relaxed);
-            const int parked = (C::st_of(ow) == C::RUNNING || C::st_of(ow) == C::DONE) ? (int)cb.ring[b ^ 1].readers.load(std::memory_order_relaxed) : 0;
+            int parked = 0;
+            for (int k = 0; k < C::NRINGS; k++) {
+                if (k == b) continue;
+                const uint64_t ow = cb.ring[k].word.load(std::memory_order_relaxed);
+                if (C::st_of(ow) == C::RUNNING || C::st_of(ow) == C::DONE) parked += (int)cb.ring[k].readers.load(std::memory_order_relaxed);
+            }
             const uint32_t j = C::joined_of(r.word.load(std::memory_order_relaxed));
             if ((int)j + parked >= cb.inside.load(std::memory_order_relaxed)) break;
             if (j != last) {
@@ -876,7 +893,21 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         if (e == hipSuccess)
             e = launch_trace_batch(s->dev, static_cast<const float*>(r.dev), cnt, reinterpret_cast<CgrtHitDev*>(static_cast<char*>(r.dev) + off_hits),
                                    reinterpret_cast<float*>(static_cast<char*>(r.dev) + off_nrm), nullptr, r.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(r.stream);
+        if (e == hipSuccess) {
+            // The leader sleeps in hipStreamSynchronize.  Polling hipStreamQuery instead was measured and is worse at every thread
+            // count (1 caller 22 us per call against 15; 64 callers 0.45 M calls/s against 0.52 M; profiles/r3_per_ray.txt): the
+            // query is itself a runtime call that the other ring's leader competes with.  CGRT_COMBINE_WAIT=0 selects the polling.
+            static const bool blocking = [] {
+                const char* w = getenv("CGRT_COMBINE_WAIT");
+                return !(w && w[0] == '0');
+            }();
+            if (blocking) {
+                e = hipStreamSynchronize(r.stream);
+            } else {
+                while ((e = hipStreamQuery(r.stream)) == hipErrorNotReady)
+                    for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+            }
+        }
         if (e != hipSuccess) {
             rc = CGRT_E_HIP;
             r.err = std::string("combined launch: ") + hipGetErrorString(e);
@@ -885,13 +916,10 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         cb.ns_gpu.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_closed).count(),
                             std::memory_order_relaxed);
         r.word.store(C::pack(C::DONE, joined, cnt, gen), std::memory_order_release);
+        r.done_gen.store(gen + 1u, std::memory_order_release);
     } else {
         unsigned sp = 0;
-        for (;;) {
-            const uint64_t w = r.word.load(std::memory_order_acquire);
-            if (C::st_of(w) == C::DONE && (w >> 32) == gen) break;
-            cpu_relax(sp);
-        }
+        while ((int32_t)(r.done_gen.load(std::memory_order_acquire) - gen) <= 0) cpu_relax(sp);
     }
     rc_out = r.rc;
     if (r.rc == CGRT_OK) {
@@ -906,7 +934,7 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
     }
     if (r.readers.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // last one out: the ring is free for generation gen + 1
         r.copied.store(0, std::memory_order_relaxed);
-        r.word.store(C::pack(C::FREE, 0, 0, (gen + 1) & 0xffffffffull), std::memory_order_release);
+        r.word.store(C::pack(C::FREE, 0, 0, (uint64_t)(gen + 1u)), std::memory_order_release);
     }
     return 1;
 }
@@ -1237,7 +1265,16 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     const CameraDev C = make_camera(*cam);
     CgrtScene::RenderAux& aux = s->raux;  // second stream + the events that order it against the default stream
     if (!aux.pin_counts) {
-        HIP_TRY(hipStreamCreateWithFlags(&aux.s, hipStreamNonBlocking));
+        // The second stream carries the frame's critical path (level 0's mirror list, then all of level 1), the default stream the
+        // level-0 shadow list beside it.  A higher queue priority for the critical path was measured: within the noise (Cornell
+        // 0.185 / 0.193 ms, dragon 0.468 / 0.455 ms with / without, profiles/r3_config3.txt); CGRT_AUX_PRIORITY=1 selects it.
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (numerically lower = higher priority)
+        const char* ap = getenv("CGRT_AUX_PRIORITY");
+        if (ap && ap[0] == '1')
+            HIP_TRY(hipStreamCreateWithPriority(&aux.s, hipStreamNonBlocking, prio_hi));
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&aux.s, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&aux.copy, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&aux.spawned, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&aux.traced, hipEventDisableTiming));
@@ -1267,6 +1304,11 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         HIP_TRY(launch_spawn(rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), ipix.as<int>(), n, mats, dlights.as<float>(), L,
                              1 < max_level, srays[0].as<float>(), sdist[0].as<float>(), sslot[0].as<int>(), levels.as<float>(), rays[1].as<float>(),
                              pix[1].as<int>(), dctr.as<uint32_t>(), nullptr, primary_hits));
+        // (Issuing level 0's shadow list here too, over its capacity n * L, was measured: Cornell 0.182 -> 0.179 ms, but the dragon
+        // frame 0.46 -> 0.50 ms -- a grid of 32 K workgroups for 318 K rays costs more than the round trip it saves.  It is sized
+        // exactly after the read-back, and issued FIRST: it used to start 64 us after the spawn kernel ended, behind the second
+        // stream's five launches, profiles/r3_config3_timeline.txt.)
+        HIP_TRY(hipEventRecord(aux.spawned, nullptr));
         HIP_TRY(hipStreamWaitEvent(aux.copy, aux.primary_done, 0));
         HIP_TRY(hipMemcpyAsync(aux.pin_counts, primary_hits, sizeof(uint32_t), hipMemcpyDeviceToHost, aux.copy));
         HIP_TRY(hipStreamSynchronize(aux.copy));
@@ -1288,12 +1330,15 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
             // level 2's mirror batch: none of it needs level 0's shading, all of it is sized by counts on the device -- so that
             // level 1's tail overlaps level 0's.  Deeper levels are small and often empty: they run one after the other,
             // exactly sized after each level's read-back, or not at all.
+            // the level's shadow list first: the long pole of the default stream must not wait behind the second stream's launches
+            if (L)
+                HIP_TRY(launch_trace_shadow(s->dev, srays[q].as<float>(), sdist[q].as<float>(), cnt * L, shits[q].as<CgrtHitDev>(), nullptr, ctr + 0,
+                                            cw_shadow));
             const bool overlap = spawn && level == 0;
             const bool pipelined = overlap && SL == 0;
             const int spawn1 = 2 < max_level;
             uint32_t* const ctr1 = dctr.as<uint32_t>() + 4;
-            if (overlap) {
-                HIP_TRY(hipEventRecord(aux.spawned, nullptr));
+            if (overlap) {  // (level 0: aux.spawned was recorded right behind the spawn kernel)
                 HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
                 HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cnt, hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, aux.s,
                                            ctr + 1));
@@ -1315,9 +1360,6 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
                 }
                 HIP_TRY(hipEventRecord(aux.traced, aux.s));
             }
-            if (L)
-                HIP_TRY(launch_trace_shadow(s->dev, srays[q].as<float>(), sdist[q].as<float>(), cnt * L, shits[q].as<CgrtHitDev>(), nullptr, ctr + 0,
-                                            cw_shadow));
             if (SL) {
                 Q.level = (uint32_t)level;
                 HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));

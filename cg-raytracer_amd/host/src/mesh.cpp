@@ -88,7 +88,9 @@ std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNorm
             std::vector<Corner> face;
             std::string tok;
             // An index that is not a number, is 0, or points outside the vertices / normals read so far makes the file
-            // invalid: upstream's importer refuses it ("Assimp failed to load mesh file", mesh.cpp:66-71) and throws.
+            // invalid here: it is refused the way upstream refuses a file its importer cannot load ("Assimp failed to load mesh
+            // file", mesh.cpp:66-71, then a throw).  Whether assimp 5.0.1 refuses, repairs or skips each of these cases is
+            // UNPINNED (no fixture upstream, assimp absent): the rule is this repo's -- an unresolvable index never becomes a triangle.
             auto index = [&](const std::string& t, size_t count) -> int {
                 size_t used = 0;
                 long v = 0;

@@ -17,7 +17,8 @@ W = H = 800
 cam = pkg.scenes.default_camera(W, H)
 rays = orc.generate_rays(cam, W, H)
 print(f"host cores: {os.cpu_count()}; scene monkey-rotated.obj ({sd.ntris} triangles), {W}x{H}")
-for combining in (False, True):
+QUICK = os.environ.get("PER_RAY_QUICK") == "1"  # only the call-rate table with combining on
+for combining in ((True,) if QUICK else (False, True)):
     pkg.set_call_combining(combining)
     for T in (1, 8, 64, 256):
         n = min(len(rays), 4000 * T if combining else 1500 * T)
@@ -27,6 +28,8 @@ for combining in (False, True):
               + (f"; {tim['combined_rays'] / max(1, tim['combined_generations']):.1f} rays per launch on average (largest {tim['largest_generation']}), "
                  f"{tim['leader_gpu_us_per_generation']:.1f} us launch + kernel + wait per launch" if combining else ""), flush=True)
 pkg.set_call_combining(True)
+if QUICK:
+    sys.exit(0)
 o2 = orc.OracleScene(sd)
 t0 = time.time()
 ref, nrays = o2.render(cam, W, H, sd.point_lights, max_level=2)
