@@ -319,15 +319,17 @@ __device__ __forceinline__ uint32_t run_count(const uint32_t r) { return ((r >> 
 
 // One step through a 128-byte node of the in-leaf accelerator (four child boxes): the nearest hit child becomes `cur`,
 // the other hit children are deferred far-to-near so that they pop near-to-far.  best_t = the scan's running minimum.
-// (the node's seven quarters already loaded: a0 b0 c0 = the first half's boxes, m = the four child references, a1 b1 c1 = the second half's boxes)
 template <bool COUNT>
-__device__ __forceinline__ void sub_node_compute(const RayPre& P, const float best_t, const float4 a0, const float4 b0, const float4 c0, const uint4 m,
-                                                 const float4 a1, const float4 b1, const float4 c1, uint32_t& cur, int& sp,
-                                                 uint32_t* __restrict__ stk, LaneCounters& cnt) {
+__device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P, const float best_t, uint32_t& cur, int& sp,
+                                              uint32_t* __restrict__ stk, LaneCounters& cnt) {
         if (COUNT) {
             cnt.sub++;
             if (first_active_lane()) cnt.w_sub++;
         }
+        const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
+        const float4 a0 = q[0], b0 = q[1], c0 = q[2];
+        const uint4 m = *reinterpret_cast<const uint4*>(q + 3);  // the four child references (cgrt_layout.h SubNode)
+        const float4 a1 = q[4], b1 = q[5], c1 = q[6];
         float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
         slab_cons4(P, a0, b0, c0, a1, b1, c1, tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3);
         // Bound for culling: the running minimum, but never below 0 -- an origin-on-plane acceptance
@@ -371,15 +373,6 @@ __device__ __forceinline__ void sub_node_compute(const RayPre& P, const float be
         sp += (k1 < inf) ? 1 : 0;
         cur = (k0 < inf) ? r0 : REF_NONE;
     }
-template <bool COUNT>
-__device__ __forceinline__ void sub_node_step(const SceneDev& S, const RayPre& P, const float best_t, uint32_t& cur, int& sp,
-                                              uint32_t* __restrict__ stk, LaneCounters& cnt) {
-    const float4* q = reinterpret_cast<const float4*>(S.subnodes + cur);
-    const float4 a0 = q[0], b0 = q[1], c0 = q[2];
-    const uint4 m = *reinterpret_cast<const uint4*>(q + 3);  // the four child references (cgrt_layout.h SubNode)
-    const float4 a1 = q[4], b1 = q[5], c1 = q[6];
-    sub_node_compute<COUNT>(P, best_t, a0, b0, c0, m, a1, b1, c1, cur, sp, stk, cnt);
-}
 // intersectLeaf (bvh.cpp:535-553) for one ray.  "while-while": lanes first step through accelerator nodes
 // until each stands on a run of triangles (or has nothing left), then the runs are tested together.
 // Stack entries are bare references (carrying the entry parameter for culling on pop was measured: no gain).
