@@ -28,9 +28,6 @@ using namespace cgrt;
 static_assert(sizeof(CgrtRay) == 28, "CgrtRay must match the reference Ray (ray.h:9-13)");
 static_assert(sizeof(CgrtHit) == sizeof(CgrtHitDev), "CgrtHit layout");
 
-#ifndef CGRT_TAIL_SPLIT_MAX_PIXELS
-#define CGRT_TAIL_SPLIT_MAX_PIXELS 0ull  // frames / frame shares of at most this many pixels split their tails by default (set from measurements)
-#endif
 namespace {
 
 thread_local std::string g_err;
@@ -39,7 +36,6 @@ thread_local std::string g_err;
 std::mutex g_options_mutex;
 BuildOptions g_build_options;
 std::atomic<int> g_call_combining{1};  // cgrt_set_call_combining
-std::atomic<int> g_tail_split{-1};     // cgrt_set_tail_split: -1 = by launch size, 0 = never, 1 = every frame of a scene with a fast tree
 std::atomic<int> g_primary_mode{0};  // 0 = one wave per tile, 1 = persistent waves with lane refill
 
 int fail(int code, const std::string& msg) {
@@ -162,13 +158,6 @@ struct CgrtScene {
     unsigned int* d_queues = nullptr;  // ring of 8 queue blocks (CGRT_QUEUE_BLOCK_WORDS u32 each) for the persistent kernel, reset by every launch
     // the persistent kernel's launches take the queue blocks in turn; a block is handed to a new launch only behind the
     // launch that used it last (an event per block), so any number of frames may be in flight on any streams
-    // Tail splitting (cgrt_layout.h SpillBox): four sets of {control block, one mailbox per helper wave}, handed to the frame
-    // launches in turn like the queue blocks above (a set is reused only behind the launch that used it last); allocated on first use
-    void* d_spill = nullptr;
-    size_t spill_set_bytes = 0;
-    uint32_t spill_helpers = 0, spill_groups = 0;
-    unsigned spill_seq = 0;
-    hipEvent_t spill_done[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex queue_mutex;
     unsigned launch_seq = 0;
     hipEvent_t queue_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -260,10 +249,8 @@ struct CgrtScene {
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues, d_spill})
+        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues})
             if (p) (void)hipFree(p);
-        for (hipEvent_t e : spill_done)
-            if (e) (void)hipEventDestroy(e);
         if (pin_frame) (void)hipHostFree(pin_frame);
         for (hipEvent_t e : {raux.spawned, raux.traced, raux.e0, raux.e1, raux.primary_done})
             if (e) (void)hipEventDestroy(e);
@@ -961,11 +948,6 @@ int cgrt_debug_combiner_stats(const CgrtScene* s, uint64_t* out4) {
     out4[3] = s->comb.ns_gpu.load();
     return CGRT_OK;
 }
-int cgrt_set_tail_split(int mode) {
-    if (mode < -1 || mode > 1) return fail(CGRT_E_ARG, "mode must be -1 (by launch size), 0 (never) or 1 (every frame)");
-    g_tail_split.store(mode);
-    return CGRT_OK;
-}
 int cgrt_set_call_combining(int enabled) {
     g_call_combining.store(enabled ? 1 : 0);
     return CGRT_OK;
@@ -1047,53 +1029,7 @@ static int launch_primary(CgrtScene* s, const CameraDev& C, const FrameDev& F, C
         HIP_TRY(launch_trace_primary_persistent(s->dev, C, F, d_hits, d_normals, counters, q, s->persistent_blocks, stream));
         HIP_TRY(hipEventRecord(s->queue_done[k], stream));
     } else {
-        // Tail splitting (DESIGN.md "Tail splitting"): by default for launches small enough that their time is their hardest tiles'
-        static const int env_split = [] {
-            const char* e = getenv("CGRT_TAIL_SPLIT");  // experiment knob: -1 / 0 / 1
-            return e ? atoi(e) : -2;
-        }();
-        static const unsigned long long env_split_max = [] {
-            const char* e = getenv("CGRT_TAIL_SPLIT_MAX");
-            return e ? strtoull(e, nullptr, 10) : 0ull;
-        }();
-        const int mode = env_split != -2 ? env_split : g_tail_split.load();
-        const unsigned long long npix = (unsigned long long)F.nblocks * 64ull;
-        const bool split = s->dev.fast_root != REF_NONE && F.block == 64 && mode != 0 &&
-                           (mode > 0 || npix <= (env_split_max ? env_split_max : (unsigned long long)CGRT_TAIL_SPLIT_MAX_PIXELS));
-        if (split) {
-            std::lock_guard<std::mutex> lk(s->queue_mutex);
-            if (!s->d_spill) {
-                s->spill_helpers = s->persistent_blocks;  // one helper wave per SIMD
-                if (const char* e = getenv("CGRT_SPILL_HELPERS")) s->spill_helpers = (uint32_t)std::max(1, atoi(e));  // experiment knob
-                s->spill_groups = 8192;                   // queue capacity: 32 K rays per launch
-                s->spill_set_bytes = ((sizeof(SpillCtl) + 255) & ~(size_t)255) + (size_t)s->spill_groups * sizeof(SpillGroup);
-                HIP_TRY(hipMalloc(&s->d_spill, 4 * s->spill_set_bytes));
-                HIP_TRY(hipMemset(s->d_spill, 0, 4 * s->spill_set_bytes));
-            }
-            const unsigned k = s->spill_seq++ & 3u;
-            if (s->spill_done[k])
-                HIP_TRY(hipStreamWaitEvent(stream, s->spill_done[k], 0));  // the set's previous launch, on whatever stream it ran
-            else
-                HIP_TRY(hipEventCreateWithFlags(&s->spill_done[k], hipEventDisableTiming));
-            SpillDev SP;
-            char* base = static_cast<char*>(s->d_spill) + (size_t)k * s->spill_set_bytes;
-            SP.ctl = reinterpret_cast<SpillCtl*>(base);
-            SP.group = reinterpret_cast<SpillGroup*>(base + ((sizeof(SpillCtl) + 255) & ~(size_t)255));
-            SP.ngroups = s->spill_groups;
-            SP.nhelpers = s->spill_helpers;
-            static const unsigned sp_first = [] { const char* e = getenv("CGRT_SPILL_FIRST"); return e ? (unsigned)atoi(e) : 8u; }();
-            static const unsigned sp_every = [] { const char* e = getenv("CGRT_SPILL_EVERY"); return e ? (unsigned)atoi(e) : 4u; }();
-            static const unsigned sp_keep = [] { const char* e = getenv("CGRT_SPILL_KEEP"); return e ? (unsigned)atoi(e) : 4u; }();
-            SP.first = sp_first ? sp_first : 1u;
-            SP.every = sp_every ? sp_every : 1u;
-            SP.keep = sp_keep;
-            SP.gen = ((s->spill_seq & 0x3fffffffu) ? (s->spill_seq & 0x3fffffffu) : 1u) << 2;  // (never 0) states of other launches never match
-            HIP_TRY(hipMemsetAsync(SP.ctl, 0, 128, stream));  // reserve / claim start at 0 (the slow-wave counters return to 0 by themselves)
-            HIP_TRY(launch_trace_primary(s->dev, C, F, d_hits, d_normals, counters, stream, &SP));
-            HIP_TRY(hipEventRecord(s->spill_done[k], stream));
-        } else {
-            HIP_TRY(launch_trace_primary(s->dev, C, F, d_hits, d_normals, counters, stream));
-        }
+        HIP_TRY(launch_trace_primary(s->dev, C, F, d_hits, d_normals, counters, stream));
     }
     return CGRT_OK;
 }

@@ -144,55 +144,6 @@ struct SceneDev {
     uint32_t nleaves;
 };
 
-// ---- tail splitting (walk_fast.h "spill", trace_kernels.hip helper waves; DESIGN.md "Tail splitting") ----
-// A small frame launch carries, behind its tile workgroups, `nhelpers` single-wave HELPER workgroups; the dispatcher reaches them
-// when every tile has been started, i.e. when the chip begins to idle.  A tile wave that is still busy after a number of loop
-// trips appends most of its live rays, WITH their search state (scan state + stack), to a queue in groups of four and goes on
-// with the rest; helpers take groups off the queue, finish each ray with 16 lanes (walk_quad.h) and write its result.  When the
-// tile wave has finished its own rays it takes back whichever of its groups nobody has claimed and finishes them itself, so
-// the result never depends on a helper being there: helpers may come late and leave early.  The search is order-free, so who
-// finishes a ray does not change its answer.  Tile waves never wait and never poll.
-// All protocol words are read and written with relaxed agent-scope accesses (they bypass the XCDs' L2s, which are not coherent
-// with each other); a producer issues ONE release fence between writing its groups and publishing them.
-struct SpillRay {  // 64 words
-    float o[3], d[3];
-    float t0;            // ray.t the search started from
-    float best_t;        // FastScan
-    uint32_t best_rec;
-    uint32_t flags;      // bit 0 tie, bit 1 onp
-    uint32_t out_lo, out_hi;  // index of the result (pixel, or position in the packed order)
-    uint32_t sp;         // stack entries that follow (the node or run the lane stood on included)
-    uint32_t pad[3];
-    uint32_t stack[48];
-};
-static_assert(sizeof(SpillRay) == 256, "SpillRay must be 256 B");
-static const uint32_t SPILL_RAYS = 4;  // rays per group = rows of 16 lanes in a helper wave
-enum { SPILL_READY = 1, SPILL_CLAIMED = 2 };
-struct SpillGroup {
-    uint32_t state;    // (launch generation << 2) | SPILL_READY once the rays are in memory, | SPILL_CLAIMED once somebody finishes them
-    uint32_t pad[15];
-    SpillRay ray[SPILL_RAYS];
-};
-static_assert(sizeof(SpillGroup) == 64 + 4 * 256, "SpillGroup layout");
-struct SpillCtl {      // counters of one launch, each on a line of its own (zeroed before the launch)
-    uint32_t reserve;  // groups reserved by producers (may exceed the capacity: those beyond it do not exist)
-    uint32_t pad0[15];
-    uint32_t claim;    // groups handed to helpers so far
-    uint32_t pad1[15];
-    struct {
-        uint32_t n;    // tile waves that are past their first loop trips and not finished (the ones that may still hand rays over), in
-        uint32_t pad[15];  // eight residue classes of blockIdx: helpers that find nothing to do leave once all eight are zero
-    } slow[8];
-};
-struct SpillDev {      // kernel argument
-    SpillCtl* ctl;
-    SpillGroup* group;
-    uint32_t ngroups;  // capacity of the queue
-    uint32_t nhelpers;
-    uint32_t gen;      // launch generation, pre-shifted by 2 (never 0): states of other launches never match
-    uint32_t first, every, keep;  // a tile wave hands rays over after `first` loop trips, then every `every` trips, keeping >= `keep`
-};
-
 // Camera constants evaluated once on the host (trackball.cpp:70-73, :92-103): position, quaternion,
 // half extents of the image plane.  The per-pixel part runs on the device.
 struct CameraDev {

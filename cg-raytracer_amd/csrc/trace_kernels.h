@@ -32,10 +32,8 @@ void set_quad_shape(int mode, unsigned long long max_rays);
 void get_quad_shape(int* mode, unsigned long long* max_rays);
 bool quad_shape_for(const SceneDev& S, unsigned long long rays);
 // counters (optional): 5 x u64 device words {rays, inner_visits, leaf_visits, tri_tests, sub_visits}, accumulated.
-// spill (optional): tail splitting -- the launch carries spill->nhelpers helper workgroups behind the tiles' (cgrt_layout.h SpillBox);
-// the control block must be zero and no other launch may use the same boxes at the same time
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
-                                unsigned long long* counters, hipStream_t stream, const SpillDev* spill = nullptr);
+                                unsigned long long* counters, hipStream_t stream);
 // persistent variant: queue = CGRT_QUEUE_BLOCK_WORDS zeroed u32 (8 heads + exit counter, one 128-B line each) owned by this launch; blocks = persistent grid size
 hipError_t launch_trace_primary_persistent(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
                                            unsigned long long* counters, unsigned int* queue, unsigned blocks, hipStream_t stream);

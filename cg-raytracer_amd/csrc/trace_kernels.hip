@@ -40,174 +40,28 @@ __device__ __forceinline__ bool frame_pixel(const FrameDev& F, int& x, int& y, s
     return tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y);
 }
 
-// ---- tail splitting: finishing handed-over rays (cgrt_layout.h SpillGroup, walk_fast.h spill_rays) ----
-// The four rays of group G, from their saved state: 16 lanes per ray (walk_quad.h quad_wide_tail), certificate, exact walk when
-// there is none, result.  Called by all 64 lanes of a wave that has claimed the group.
-template <bool COUNT>
-__device__ __forceinline__ void spill_finish_group(const SceneDev& S, const SpillGroup* G, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
-                                                   uint32_t* __restrict__ wave_stk, LaneCounters& cnt) {
-    const int lane = threadIdx.x & 63, Q = lane >> 2, q = lane & 3;
-    // quad Q < 4 carries ray Q, all four lanes the same values; loaded past the caches like everything of the protocol
-    const bool mine = Q < (int)SPILL_RAYS;
-    const SpillRay* R = G->ray + (mine ? Q : 0);
-    Walk W;
-    W.o = f3(__uint_as_float(spill_load((const uint32_t*)&R->o[0])), __uint_as_float(spill_load((const uint32_t*)&R->o[1])),
-             __uint_as_float(spill_load((const uint32_t*)&R->o[2])));
-    W.d = f3(__uint_as_float(spill_load((const uint32_t*)&R->d[0])), __uint_as_float(spill_load((const uint32_t*)&R->d[1])),
-             __uint_as_float(spill_load((const uint32_t*)&R->d[2])));
-    W.t = __uint_as_float(spill_load((const uint32_t*)&R->t0));
-    W.hit_rec = REF_NONE;
-    W.cur = S.root_ref;
-    W.sp = 0;
-    W.P = make_raypre(S, W.o, W.d, W.t);
-    FastScan F;
-    F.best_t = __uint_as_float(spill_load((const uint32_t*)&R->best_t));
-    F.best_rec = spill_load(&R->best_rec);
-    const uint32_t fl = spill_load(&R->flags);
-    F.tie = (fl & 1u) != 0u;
-    F.onp = (fl & 2u) != 0u;
-    const int sp = mine ? (int)spill_load(&R->sp) : 0;
-    const unsigned long long out = (unsigned long long)spill_load(&R->out_lo) | ((unsigned long long)spill_load(&R->out_hi) << 32);
-    uint32_t* __restrict__ stkq = wave_stk + Q * CGRT_QSLOTS;
-    const bool search = mine && sp <= CGRT_QSLOTS;  // (a deeper stack than the quad layout holds: exact walk)
-    if (search)
-        for (int i = q; i < sp; i += 4) stkq[i] = spill_load(&R->stack[i]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    bool tail_failed = false;
-    quad_wide_tail<COUNT, WALK_CLOSEST>(S, __ballot(search && q == 0), search, W, 0.0f, F, REF_NONE, sp, tail_failed, wave_stk, cnt);
-    bool certified = search && !tail_failed && !F.onp && !F.tie;
-    if (certified && F.best_rec != REF_NONE) {
-        const uint32_t cert0 = cnt.cert;
-        certified = path_certified<COUNT>(S, W, F.best_rec, F.best_t, cnt);
-        if (COUNT && q != 0) cnt.cert = cert0;
-        if (certified) {
-            W.t = F.best_t;
-            W.hit_rec = F.best_rec;
-        }
-    }
-    if (COUNT && mine && !certified && q == 0) cnt.fallback++;
-    if (mine && !certified && q == 0) {  // no certificate: the exact walk from the root, one lane per ray
-        W.P = make_raypre(S, W.o, W.d, W.t);
-        W.R = make_rayfast(S, W.o, W.d);
-        walk_tree_unified<COUNT, false>(S, W, wave_stk + (threadIdx.x & 63u), cnt);
-    }
-    if (mine && q == 0) finish_ray(S, W.o, W.d, W.t, W.hit_rec, hits + out, normals ? normals + 3 * out : nullptr);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-}
-// one lane claims group g (READY -> CLAIMED); true for the whole wave when it got it
-__device__ __forceinline__ bool spill_claim(const SpillDev& SP, const uint32_t g) {
-    uint32_t ok = 0u;
-    if ((threadIdx.x & 63u) == 0u) ok = atomicCAS(&SP.group[g].state, SP.gen | SPILL_READY, SP.gen | SPILL_CLAIMED) == (SP.gen | SPILL_READY) ? 1u : 0u;
-    return __shfl((int)ok, 0, 64) != 0;
-}
-// A helper wave: takes groups off the queue as long as there are any; with nothing to do it leaves as soon as no tile wave is
-// left that could still hand rays over (or after ~50 us of idling whatever the counters say) -- the tile waves finish what nobody
-// claimed themselves, so leaving early costs speed only.
-template <bool COUNT>
-__device__ __forceinline__ void spill_helper(const SceneDev& S, const SpillDev& SP, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
-                                             uint32_t* __restrict__ wave_stk, LaneCounters& cnt) {
-    const int lane = threadIdx.x & 63;
-    uint32_t idle = 0;
-    for (uint32_t served = 0; served < 65536u;) {
-        // one lane looks at the queue (relaxed agent-scope loads: no cache is invalidated by looking)
-        uint32_t g = 0xffffffffu;
-        if (lane == 0) {
-            uint32_t r = spill_load(&SP.ctl->reserve);
-            r = r < SP.ngroups ? r : SP.ngroups;
-            if (spill_load(&SP.ctl->claim) < r) {
-                g = atomicAdd(&SP.ctl->claim, 1u);
-                if (g >= r) g = 0xfffffffeu;  // somebody else got the last one (the ticket is lost: its group goes back to its owner)
-            }
-        }
-        g = (uint32_t)__shfl((int)g, 0, 64);
-        if (g < SP.ngroups) {
-            // the producer publishes a moment after reserving: a short, bounded wait for READY, then the claim
-            bool got = false;
-            for (int k = 0; k < 64 && !got; k++) {
-                uint32_t st = lane == 0 ? spill_load(&SP.group[g].state) : 0u;
-                st = (uint32_t)__shfl((int)st, 0, 64);
-                if (st == (SP.gen | SPILL_READY)) {
-                    got = spill_claim(SP, g);
-                    break;
-                }
-                if (st == (SP.gen | SPILL_CLAIMED)) break;  // its owner has taken it back already
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (got) {
-                spill_finish_group<COUNT>(S, SP.group + g, hits, normals, wave_stk, cnt);
-                served++;
-                idle = 0;
-            }
-            continue;
-        }
-        // nothing to take: is anybody left who could still hand rays over?
-        uint32_t slow = 0u;
-        if (lane < 8) slow = spill_load(&SP.ctl->slow[lane].n);
-        if (__ballot(slow != 0u) == 0ull || ++idle > 24u) return;
-        __builtin_amdgcn_s_sleep(127);  // ~3 us
-    }
-}
-
-template <bool COUNT, bool FAST, bool QUAD, bool SPILL>
-__device__ __forceinline__ void trace_primary_body(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* __restrict__ hits,
-                                                   float* __restrict__ normals, unsigned long long* counters, const SpillDev& SP) {
+template <bool COUNT, bool FAST, bool QUAD = false>
+__global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
+                                        unsigned long long* counters) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
-    LaneCounters cnt;
-    if (SPILL && blockIdx.x >= F.nblocks) {  // a helper wave (single-wave workgroups behind the tiles')
-        spill_helper<COUNT>(S, SP, hits, normals, CGRT_WAVE_STACK(s_lds), cnt);
-        if (COUNT) flush_counters(cnt, false, counters);
-        return;
-    }
     int x = 0, y = 0;
     size_t pidx;
     bool writer;
     const bool active = frame_pixel<QUAD>(F, x, y, pidx, writer);
+    LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
     float t = 3.402823466e+38f;  // std::numeric_limits<float>::max(), trackball.cpp:101
     uint32_t hit_rec = REF_NONE;
-    bool handed_over = false;
-    SpillOut so;
     if (QUAD)
         walk_tree_quad<COUNT>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), cnt);
     else
-        handed_over = walk_tree<COUNT, FAST, WALK_CLOSEST, SPILL>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt, 0.0f, &SP,
-                                                                   F.packed ? (unsigned long long)pidx : (unsigned long long)y * F.W + x, &so);
-    if (active && writer && !handed_over) {
+        walk_tree<COUNT, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
+    if (active && writer) {
         const size_t pix = F.packed ? pidx : (size_t)y * F.W + x;
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
-    if (SPILL) {  // whatever this wave handed over and nobody has claimed comes back to it
-        const uint32_t gfirst = (uint32_t)__shfl((int)so.first, 0, 64), gn = (uint32_t)__shfl((int)so.n, 0, 64);
-        if (gn) {
-            // one look at all of them at once (lane k at group k), then a claim only for those still unclaimed -- usually none
-            const uint32_t lane_ = threadIdx.x & 63u;
-            const bool left = lane_ < gn && spill_load(&SP.group[gfirst + lane_].state) == (SP.gen | SPILL_READY);
-            unsigned long long todo = __ballot(left);
-            while (todo) {
-                const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
-                todo &= todo - 1ull;
-                if (spill_claim(SP, gfirst + k)) spill_finish_group<COUNT>(S, SP.group + gfirst + k, hits, normals, CGRT_WAVE_STACK(s_lds), cnt);
-            }
-        }
-    }
     if (COUNT) flush_counters(cnt, active && writer, counters);
-}
-template <bool COUNT, bool FAST, bool QUAD = false>
-__global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
-                                        unsigned long long* counters) {
-    SpillDev none{};
-    trace_primary_body<COUNT, FAST, QUAD, false>(S, C, F, hits, normals, counters, none);
-}
-// The tail-splitting variant (small launches only): tile waves + helper waves in one launch.  It may use more registers than the
-// three-waves-per-SIMD budget of the other kernels (a small launch does not fill the SIMDs anyway) rather than spill to scratch: a
-// kernel with a scratch segment pays for it at every dispatch.
-template <bool COUNT>
-__global__ __launch_bounds__(CGRT_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_trace_primary_split(SceneDev S, CameraDev C, FrameDev F,
-                                                                                                             CgrtHitDev* __restrict__ hits,
-                                                                                                             float* __restrict__ normals,
-                                                                                                             unsigned long long* counters, SpillDev SP) {
-    trace_primary_body<COUNT, true, false, true>(S, C, F, hits, normals, counters, SP);
 }
 
 // Primary frame for the shading wavefront (cgrt_render): the fused kernel's walk, but only the rays that HIT are written,
@@ -530,7 +384,7 @@ bool quad_shape_for(const SceneDev& S, unsigned long long rays) {  // frames: th
 }
 
 hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const FrameDev& F, CgrtHitDev* hits, float* normals,
-                                unsigned long long* counters, hipStream_t stream, const SpillDev* spill) {
+                                unsigned long long* counters, hipStream_t stream) {
     if (F.nblocks == 0) return hipSuccess;
     const bool fast = S.fast_root != REF_NONE;
     if (F.block == 64 && quad_shape_for(S, (unsigned long long)F.nblocks * 64ull)) {
@@ -538,14 +392,6 @@ hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const Fra
             CGRT_LAUNCHQ(k_trace_primary, true, 4u * F.nblocks, stream, S, C, F, hits, normals, counters);
         else
             CGRT_LAUNCHQ(k_trace_primary, false, 4u * F.nblocks, stream, S, C, F, hits, normals, counters);
-        return hipGetLastError();
-    }
-    if (spill && fast && F.block == 64 && spill->nhelpers > 0) {  // tail splitting: helper workgroups behind the tiles'
-        const unsigned grid = F.nblocks + spill->nhelpers;
-        if (counters)
-            hipLaunchKernelGGL((k_trace_primary_split<true>), dim3(grid), dim3(64), lds_bytes(64), stream, S, C, F, hits, normals, counters, *spill);
-        else
-            hipLaunchKernelGGL((k_trace_primary_split<false>), dim3(grid), dim3(64), lds_bytes(64), stream, S, C, F, hits, normals, counters, *spill);
         return hipGetLastError();
     }
     if (counters)

@@ -338,65 +338,9 @@ __device__ __forceinline__ void quad_tail(const SceneDev& S, const unsigned long
 // envelope (W.P.regular) and wants the certified walk; the other lanes only help in the quad tail.  Must be called
 // by all 64 lanes (wave-uniform control flow).  Returns, per alive lane, true when (W.t, W.hit_rec) now hold the answer the
 // MODE asks for (see WALK_*); false: W is untouched, take the exact walk.  qlen: WALK_OCCLUDED's |fromPosToLight|.
-// ---- tail splitting: the tile wave's side (cgrt_layout.h SpillGroup; the helper's side is in trace_kernels.hip) ----
-// (SpillDev::first / every / keep: a wave that is still busy after `first` loop trips hands rays over, then every `every` trips,
-// keeping at least `keep` of its live rays for itself)
-__device__ __forceinline__ uint32_t spill_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void spill_store(uint32_t* p, const uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void spill_store(float* p, const float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Appends all but CGRT_SPILL_KEEP of the wave's live rays (a multiple of four), with their search state, to the launch's queue.
-// live: ballot of the lanes with an unfinished ray; (F, cur, sp) + the lane's LDS stack = that ray's state.  Lanes whose ray went
-// return true (they are finished here: a helper writes their result at out_index).  Called by all 64 lanes; waits for nothing
-// but its own memory operations.
-// spilled_first / spilled_n (wave-uniform, out): the groups this call appended (the wave takes unclaimed ones back at its end).
-__device__ __forceinline__ bool spill_rays(const SpillDev& SP, const unsigned long long live, const bool mine, const Walk& W, const FastScan& F,
-                                           const uint32_t cur, const int sp, const uint32_t* __restrict__ stk, const unsigned long long out_index,
-                                           uint32_t& spilled_first, uint32_t& spilled_n) {
-    const int lane = threadIdx.x & 63;
-    const int ng = ((int)__popcll(live) - (int)SP.keep) / (int)SPILL_RAYS;
-    if (ng <= 0) return false;
-    uint32_t first = 0;
-    if (lane == 0) first = atomicAdd(&SP.ctl->reserve, (uint32_t)ng);
-    first = (uint32_t)__shfl((int)first, 0, 64);
-    if (first + (uint32_t)ng > SP.ngroups) return false;  // the queue is full (the reservation beyond its end is never looked at)
-    // the first 4 * ng live lanes go (any choice is as good as another: who finishes a ray does not change its answer)
-    const int rank = (int)__popcll(live & ((1ull << lane) - 1ull));
-    const bool go = mine && rank < (int)SPILL_RAYS * ng;
-    if (go) {
-        SpillRay* R = SP.group[first + (uint32_t)(rank >> 2)].ray + (rank & 3);
-        spill_store(&R->o[0], W.o.x), spill_store(&R->o[1], W.o.y), spill_store(&R->o[2], W.o.z);
-        spill_store(&R->d[0], W.d.x), spill_store(&R->d[1], W.d.y), spill_store(&R->d[2], W.d.z);
-        spill_store(&R->t0, W.t);
-        spill_store(&R->best_t, F.best_t);
-        spill_store(&R->best_rec, F.best_rec);
-        spill_store(&R->flags, (F.tie ? 1u : 0u) | (F.onp ? 2u : 0u));
-        spill_store(&R->out_lo, (uint32_t)out_index);
-        spill_store(&R->out_hi, (uint32_t)(out_index >> 32));
-        int n = 0;
-        for (; n < sp; n++) spill_store(&R->stack[n], stk[n * CGRT_STRIDE]);
-        if (cur != REF_NONE) spill_store(&R->stack[n++], cur);  // the node or run the lane stands on is the top entry
-        spill_store(&R->sp, (uint32_t)n);
-    }
-    // The rays are in memory before any group says so.  Every word above was stored past the L2 (agent scope), so all that is needed
-    // is to wait for those stores -- NOT a release fence, whose L2 write-back stalls the whole XCD (measured: a hand-over cost
-    // hundreds of microseconds with it).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (go && (rank & 3) == 0) spill_store(&SP.group[first + (uint32_t)(rank >> 2)].state, SP.gen | SPILL_READY);
-    spilled_first = first;
-    spilled_n = (uint32_t)ng;
-    return go;
-}
-
-// out_index / spilled: only with SPILL (frames): where the lane's result goes, and whether a helper wave took the ray over (the
-// lane is then finished: nothing more to do for it in this wave).
-struct SpillOut {   // what a tile wave handed over (wave-uniform), and whether this lane's ray was among it
-    uint32_t first = 0, n = 0;
-    bool lane_gone = false;
-};
-template <bool COUNT, int MODE, bool SPILL = false>
+template <bool COUNT, int MODE>
 __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool alive, Walk& W, const float qlen, uint32_t* __restrict__ wave_stk,
-                                               uint32_t* __restrict__ s_map, LaneCounters& cnt, const SpillDev* SP = nullptr,
-                                               const unsigned long long out_index = 0ull, SpillOut* spilled = nullptr) {
+                                               uint32_t* __restrict__ s_map, LaneCounters& cnt) {
     uint32_t* __restrict__ stk = wave_stk + (threadIdx.x & 63u);
     const F3 o = W.o, d = W.d;
     FastScan F;
@@ -408,9 +352,6 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
     uint32_t cur = alive ? S.fast_root : REF_NONE;
     int sp = 0;
     bool done = !alive, failed = false;
-    uint32_t trips = 0, sp_first = 0, sp_n = 0;
-    bool gone = false;  // SPILL: this lane's ray was handed over
-    bool slow = false;  // SPILL: the wave has registered as one that may still hand rays over
     for (;;) {
         const unsigned long long live = __ballot(!done);
         if (live == 0ull) break;
@@ -438,33 +379,6 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
                 }
             }
         }
-        if (SPILL) {
-            // A wave that is still busy after CGRT_SPILL_FIRST trips of a SMALL launch (the only kind that carries helpers: every
-            // tile has been started by then and the helper waves behind them are running or about to) hands its rays over.  It
-            // does not look whether anybody is there to take them: a poll that bypasses the L2 would cost every trip a trip's time.
-            trips += 1;
-            if (trips == (SP->first + 1u) / 2u) {  // half way to its first hand-over: helpers with nothing to do wait for this wave
-                slow = true;
-                if ((threadIdx.x & 63u) == 0u) atomicAdd(&SP->ctl->slow[blockIdx.x & 7u].n, 1u);
-            }
-            if (sp_n == 0u && trips >= SP->first && (trips - SP->first) % SP->every == 0u) {  // (one hand-over per wave)
-                const unsigned long long still = __ballot(!done);
-                if ((int)__popcll(still) >= (int)SP->keep + (int)SPILL_RAYS) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    if (spill_rays(*SP, still, !done, W, F, cur, sp, stk, out_index, sp_first, sp_n)) {
-                        done = true;
-                        gone = true;
-                    }
-                }
-            }
-        }
-    }
-    if (SPILL) {
-        if (slow && (threadIdx.x & 63u) == 0u) atomicSub(&SP->ctl->slow[blockIdx.x & 7u].n, 1u);
-        spilled->first = sp_first;
-        spilled->n = sp_n;
-        spilled->lane_gone = gone;
-        if (gone) return true;  // (W untouched; the caller skips the lane: see walk_tree)
     }
     if (!alive || failed || F.onp || (MODE == WALK_CLOSEST && F.tie)) return false;  // (a tie changes the record, not the flag)
     if (F.best_rec != REF_NONE) {
@@ -483,13 +397,10 @@ __device__ __forceinline__ bool walk_fast_wave(const SceneDev& S, const bool ali
 // up to there is the reference's, so the hit FLAG is the reference's (some acceptance happens upstream iff one happens in
 // the first leaf that has one); t and the record are those of that leaf, not the final ones -- and WALK_OCCLUDED with the
 // full closest hit.
-// SPILL (frames with helper waves): SP, out_index as in walk_fast_wave; returns true when a helper wave took the lane's ray over
-// (its result is written there: the caller must not write one).
-template <bool COUNT, bool FAST, int MODE = WALK_CLOSEST, bool SPILL = false>
-__device__ __forceinline__ bool walk_tree(const SceneDev& S, const bool active, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
+template <bool COUNT, bool FAST, int MODE = WALK_CLOSEST>
+__device__ __forceinline__ void walk_tree(const SceneDev& S, const bool active, const F3 o, const F3 d, float& t, uint32_t& hit_rec,
                                           uint32_t* __restrict__ wave_stk, uint32_t* __restrict__ s_map, LaneCounters& cnt,
-                                          const float qlen = 0.0f, const SpillDev* SP = nullptr, const unsigned long long out_index = 0ull,
-                                          SpillOut* spill_out = nullptr) {
+                                          const float qlen = 0.0f) {
     Walk W;
     W.o = o;
     W.d = d;
@@ -498,16 +409,10 @@ __device__ __forceinline__ bool walk_tree(const SceneDev& S, const bool active, 
     const bool entered = active && walk_begin(S, W);
     if (COUNT && entered) cnt.entered++;
     bool certified = false;
-    SpillOut so;
     if (FAST) {
         const bool eligible = entered && W.P.regular;
-        if (__any(eligible)) certified = walk_fast_wave<COUNT, MODE, SPILL>(S, eligible, W, qlen, wave_stk, s_map, cnt, SP, out_index, &so);
+        if (__any(eligible)) certified = walk_fast_wave<COUNT, MODE>(S, eligible, W, qlen, wave_stk, s_map, cnt);
         if (COUNT && eligible && !certified) cnt.fallback++;
-    }
-    if (SPILL) {
-        spill_out->first = so.first;  // (wave-uniform: every lane of the wave gets the same range)
-        spill_out->n = so.n;
-        if (so.lane_gone) return true;
     }
     if (entered && !certified) {
         if (FAST) {  // (the per-ray constants of the exact walk are rebuilt rather than kept alive through the search)
@@ -518,7 +423,6 @@ __device__ __forceinline__ bool walk_tree(const SceneDev& S, const bool active, 
     }
     t = W.t;
     hit_rec = W.hit_rec;
-    return false;
 }
 
 }  // namespace cgrt

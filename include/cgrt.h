@@ -124,13 +124,6 @@ int cgrt_set_primary_mode(int mode);
  * max_rays = 0 keeps the current threshold.  Process-wide. */
 int cgrt_set_kernel_shape(int mode, uint64_t max_rays);
 int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays);
-/* Tail splitting of primary frames (no counterpart upstream; DESIGN.md "Tail splitting"; results are identical, tested).  A frame
- * launch ends with its hardest tiles, one wave each, while most of the chip is already idle.  With tail splitting the launch
- * carries one HELPER wave per SIMD behind its tiles; the dispatcher reaches them when every tile has been started; a tile wave
- * that still has many live rays then hands idle helpers four rays each together with their search state, and the helpers finish
- * them with 16 lanes per ray and write their results.  mode -1 (default) = launches of at most a measured number of pixels,
- * 0 = never, 1 = every frame of a scene with a fast tree.  Process-wide. */
-int cgrt_set_tail_split(int mode);
 /* Certified walk (no counterpart upstream; DESIGN.md "Certified walk").  The exact walk takes every step of the
  * reference's ordered descent (bvh.cpp:572-758) because its culling quirks are part of the result.  A scene may also
  * carry a "fast tree" (a 4-wide tree over the reference LEAVES) and per-leaf box paths: a ray then searches the fast

@@ -159,41 +159,3 @@ def test_kernel_shape_api(pkg):
         assert pkg.kernel_shape()[0] == m
     with pytest.raises(pkg.CgrtError):
         pkg.set_kernel_shape(7)
-
-
-@pytest.mark.parametrize("ntris,W,H", [(60_000, 500, 301), (200_000, 640, 360)])
-def test_tail_splitting_of_primary_frames(pkg, orc, ntris, W, H):
-    """Tail splitting (cgrt_set_tail_split): helper waves behind the tiles take rays over from slow tile waves WITH their search
-    state and finish them with 16 lanes per ray.  Who finishes a ray must not change its answer: the frame -- hits and normals,
-    plain, rank-tiled, in the packed multi-device order -- equals the frame without helpers byte for byte, and the oracle."""
-    sd = pkg.scenes.make_dragon(ntris)
-    cam = pkg.scenes.default_camera(W, H)
-    sc = pkg.Scene(sd)
-    assert sc.walk() == 1
-    pkg.set_tail_split(0)
-    try:
-        h0, n0 = sc.trace_primary(cam, W, H, want_normals=True)
-        c0 = sc.count_primary(cam, W, H)
-        pkg.set_tail_split(1)
-        for rep in range(3):  # (which rays are handed over depends on timing: several runs)
-            h1, n1 = sc.trace_primary(cam, W, H, want_normals=True)
-            assert h0.tobytes() == h1.tobytes() and n0.tobytes() == n1.tobytes(), rep
-        c1 = sc.count_primary(cam, W, H)
-        assert c1["rays"] == c0["rays"] == W * H and c1["tree_rays"] == c0["tree_rays"] and c1["fallback_rays"] == c0["fallback_rays"]
-        for r in range(3):
-            p1, _ = sc.trace_primary(cam, W, H, rank=r, nranks=3)
-            pkg.set_tail_split(0)
-            p0, _ = sc.trace_primary(cam, W, H, rank=r, nranks=3)
-            pkg.set_tail_split(1)
-            assert p0.tobytes() == p1.tobytes()
-        sc2 = pkg.Scene(sd)
-        m1, mn1, _ = pkg.trace_primary_multi([sc, sc2], cam, W, H, want_normals=True)
-        assert m1.tobytes() == h0.tobytes()
-        hit = h0["hit"] == 1
-        assert mn1[hit].tobytes() == n0[hit].tobytes()
-    finally:
-        pkg.set_tail_split(-1)
-    ref = orc.OracleScene(sd).intersect(sc.generate_rays(cam, W, H))
-    _assert_hits_equal(h1, n1, ref, "tail-split primary frame")
-    with pytest.raises(pkg.CgrtError):
-        pkg.set_tail_split(5)
