@@ -717,7 +717,8 @@ def host_threads_test(sd: SceneData, rays7, nthreads: int = 8):
         raise RuntimeError("cgrt_host_threads_test: " + Hl.cgrt_host_last_error().decode())
     return int(bad), dict(us_per_call_one_thread=float(tim[0]), us_per_call_per_thread=float(tim[1]), calls_per_second=float(tim[2]),
                           combined_generations=int(tim[3]), combined_rays=int(tim[4]), largest_generation=int(tim[5]),
-                          leader_gpu_us_per_generation=float(tim[6]) / 1e3 / max(1.0, float(tim[3])))
+                          leader_gpu_us_per_generation=float(tim[6]) / 1e3 / max(1.0, float(tim[3])),
+                          leader_launch_us_per_generation=float(tim[7]) / 1e3 / max(1.0, float(tim[3])))
 
 
 def host_render_bmp(sd: SceneData, cam, W: int, H: int, path: str, max_level: int = 2, nreplicas: int = 1):

@@ -224,7 +224,7 @@ struct CgrtScene {
         alignas(64) std::atomic<int> ready{0};    // 0 = rings not allocated yet, 1 = usable, -1 = allocation failed (direct path for good)
         // diagnostics (cgrt_debug_combiner_stats): generations launched, rays in them, the largest generation, nanoseconds the
         // leaders spent from closing a generation to its results (launch + kernel + stream wait)
-        std::atomic<uint64_t> n_gen{0}, n_rays{0}, max_gen{0}, ns_gpu{0};
+        std::atomic<uint64_t> n_gen{0}, n_rays{0}, max_gen{0}, ns_gpu{0}, ns_launch{0};  // ns_launch: the part of ns_gpu spent issuing the launch
     } comb;
     std::mutex render_mutex;  // cgrt_render* share the workspace below: one frame per scene at a time
     unsigned persistent_blocks = 1024;  // 4 workgroups per CU
@@ -801,7 +801,8 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
             bool ok = hipSetDevice(s->device) == hipSuccess;
             for (auto& r : cb.ring) {
                 if (!ok) break;
-                hipError_t e = hipHostMalloc(&r.host, total, hipHostMallocMapped);
+                hipError_t e = hipHostMalloc(&r.host, total + 64, hipHostMallocMapped);  // (+ the completion word)
+                if (e == hipSuccess) std::memset(static_cast<char*>(r.host) + total, 0, 64);
                 if (e == hipSuccess) e = hipHostGetDevicePointer(&r.dev, r.host, 0);
                 if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
                 ok = e == hipSuccess;  // (whatever was allocated is released with the scene)
@@ -893,19 +894,40 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         if (e == hipSuccess)
             e = launch_trace_batch(s->dev, static_cast<const float*>(r.dev), cnt, reinterpret_cast<CgrtHitDev*>(static_cast<char*>(r.dev) + off_hits),
                                    reinterpret_cast<float*>(static_cast<char*>(r.dev) + off_nrm), nullptr, r.stream);
+        cb.ns_launch.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_closed).count(),
+                               std::memory_order_relaxed);
         if (e == hipSuccess) {
-            // The leader sleeps in hipStreamSynchronize.  Polling hipStreamQuery instead was measured and is worse at every thread
-            // count (1 caller 22 us per call against 15; 64 callers 0.45 M calls/s against 0.52 M; profiles/r3_per_ray.txt): the
-            // query is itself a runtime call that the other ring's leader competes with.  CGRT_COMBINE_WAIT=0 selects the polling.
-            static const bool blocking = [] {
+            // How the leader waits.  Sleeping in hipStreamSynchronize serialises the two rings: while one leader sleeps there the
+            // other leader's launch call does not return (64 callers: 35 of a generation's 61 us were spent getting the launch
+            // out, 2.3 us for a lone caller; profiles/r3_per_ray.txt), and polling hipStreamQuery is worse still.  So a one-thread
+            // kernel behind the batch writes the generation's number into the ring's pinned memory and the leader watches that
+            // word: no runtime call while it waits.  (A launch that never signals -- a fault -- is caught by the bounded spin:
+            // the leader then asks the runtime.)  CGRT_COMBINE_WAIT=1: hipStreamSynchronize, =0: hipStreamQuery polling.
+            static const int wait_mode = [] {
                 const char* w = getenv("CGRT_COMBINE_WAIT");
-                return !(w && w[0] == '0');
+                return w ? atoi(w) : 2;
             }();
-            if (blocking) {
+            if (wait_mode == 1) {
                 e = hipStreamSynchronize(r.stream);
-            } else {
+            } else if (wait_mode == 0) {
                 while ((e = hipStreamQuery(r.stream)) == hipErrorNotReady)
                     for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+            } else {
+                volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(r.host) + total);
+                uint32_t* dflag = reinterpret_cast<uint32_t*>(static_cast<char*>(r.dev) + total);
+                const uint32_t token = gen + 1u;  // (the word holds the previous generation's token, never this one's)
+                e = launch_signal(dflag, token, r.stream);
+                if (e == hipSuccess) {
+                    unsigned long long spins = 0;
+                    while (*flag != token) {
+                        __builtin_ia32_pause();
+                        if (++spins > 200000000ull) {  // seconds: something is wrong with the launch -- let the runtime say what
+                            e = hipStreamSynchronize(r.stream);
+                            break;
+                        }
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
             }
         }
         if (e != hipSuccess) {
@@ -940,12 +962,13 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
 }
 }  // namespace
 
-int cgrt_debug_combiner_stats(const CgrtScene* s, uint64_t* out4) {
+int cgrt_debug_combiner_stats(const CgrtScene* s, uint64_t* out4) {  // (five words, see include/cgrt.h)
     if (!s || !out4) return fail(CGRT_E_ARG, "NULL argument");
     out4[0] = s->comb.n_gen.load();
     out4[1] = s->comb.n_rays.load();
     out4[2] = s->comb.max_gen.load();
     out4[3] = s->comb.ns_gpu.load();
+    out4[4] = s->comb.ns_launch.load();
     return CGRT_OK;
 }
 int cgrt_set_call_combining(int enabled) {

@@ -48,6 +48,8 @@ hipError_t launch_brute_batch(const SceneDev& S, const float* rays, unsigned lon
 // pointInShadow's rays (main.cpp:104-135): hits[i] decides `hit && !(t + 0.001f >= dist[i])` like the reference's closest hit does
 hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
                                const uint32_t* dcount = nullptr, unsigned long long* counters = nullptr);
+// *flag = value (system scope) once everything queued on the stream before it has finished
+hipError_t launch_signal(uint32_t* flag, uint32_t value, hipStream_t stream);
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);
 // lit[item * nlights + l] += samples of spherical light l that reach it from item's hit point (zeroed by the caller)
 hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* rays, const CgrtHitDev* hits, const int* item_pixels,

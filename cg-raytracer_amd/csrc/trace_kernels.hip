@@ -488,6 +488,15 @@ hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* 
         CGRT_LAUNCH2(k_soft_shadow, false, fast, (unsigned)blocks, block, stream, S, Q, rays, hits, item_pixels, nthreads, lit);
     return hipGetLastError();
 }
+// One word into host-visible memory, behind whatever the stream holds: lets a host thread wait for a launch by looking at its own
+// memory instead of sleeping in a runtime call (capi.cpp combined_intersect).
+__global__ void k_signal(uint32_t* __restrict__ flag, uint32_t value) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_signal(uint32_t* flag, uint32_t value, hipStream_t stream) {
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, flag, value);
+    return hipGetLastError();
+}
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream) {
     const unsigned long long n = (unsigned long long)(x1 - x0) * (unsigned long long)(y1 - y0);
     if (n == 0) return hipSuccess;

@@ -325,7 +325,7 @@ int cgrt_host_write_bmp(const char* path, const float* rgb, int W, int H) {
 // (main.cpp:653-656).  nthreads std::threads do the same here, ray i on thread i % nthreads, one ray per call, and every
 // result is compared bit for bit with intersectBatch on the same rays.  timing (optional, 3 doubles): microseconds per
 // per-ray call on one thread, microseconds per call per thread with nthreads threads, aggregate calls per second, then the
-// library's call-combining counters over the whole test (cgrt_debug_combiner_stats): timing has 7 slots.
+// library's call-combining counters over the whole test (cgrt_debug_combiner_stats): timing has 8 slots.
 // Returns the number of disagreements (0 = pass), -1 on an exception.
 int cgrt_host_threads_test(const float* pos_nrm, uint32_t nverts, const uint32_t* tri, const uint32_t* tri_mesh, uint32_t ntris,
                            const float* materials, uint32_t nmesh, const float* rays7, uint32_t nrays, int nthreads, double* timing) {
@@ -356,7 +356,7 @@ int cgrt_host_threads_test(const float* pos_nrm, uint32_t nverts, const uint32_t
         std::vector<Ray> tr = rays;
         std::vector<HitInfo> thi(nrays);
         std::vector<uint8_t> thit(nrays);
-        uint64_t cs0[4] = {0, 0, 0, 0};
+        uint64_t cs0[5] = {0, 0, 0, 0, 0};
         (void)cgrt_debug_combiner_stats(bvh.handle(), cs0);
         const auto t0 = Clk::now();
         {
@@ -381,12 +381,13 @@ int cgrt_host_threads_test(const float* pos_nrm, uint32_t nverts, const uint32_t
             timing[0] = single_us;
             timing[1] = wall_us * nthreads / (nrays ? nrays : 1);
             timing[2] = nrays / (wall_us * 1e-6);
-            uint64_t cs[4] = {0, 0, 0, 0};  // call combining inside the library: generations, rays, largest generation, leaders' GPU ns
+            uint64_t cs[5] = {0, 0, 0, 0, 0};  // call combining inside the library: generations, rays, largest generation, leaders' GPU ns, launch ns
             (void)cgrt_debug_combiner_stats(bvh.handle(), cs);
             timing[3] = (double)(cs[0] - cs0[0]);  // (the threaded part only)
             timing[4] = (double)(cs[1] - cs0[1]);
             timing[5] = (double)cs[2];
             timing[6] = (double)(cs[3] - cs0[3]);
+            timing[7] = (double)(cs[4] - cs0[4]);
         }
         return bad;
     } catch (const std::exception& e) {

@@ -162,9 +162,10 @@ int cgrt_intersect_batch(CgrtScene* scene, const CgrtRay* rays, uint64_t n, Cgrt
 /* Call combining for small cgrt_intersect_batch calls (see "Threads" above; DESIGN.md "Per-ray boundary"): 1 = on (default),
  * 0 = every call launches for itself (round 2's behaviour).  Results are identical.  Process-wide. */
 int cgrt_set_call_combining(int enabled);
-/* Diagnostic: out4 = {combined generations launched on this scene, rays in them, rays of the largest one, nanoseconds their
- * leaders spent between closing a generation and holding its results (launch + kernel + stream wait)}. */
-int cgrt_debug_combiner_stats(const CgrtScene* scene, uint64_t* out4);
+/* Diagnostic: out5 = {combined generations launched on this scene, rays in them, rays of the largest one, nanoseconds their
+ * leaders spent between closing a generation and holding its results (waiting for the joiners' rays + launch + kernel + stream
+ * wait), the part of that up to the return of the launch call}. */
+int cgrt_debug_combiner_stats(const CgrtScene* scene, uint64_t* out5);
 /* intersectRayWithShape(const Mesh&, Ray&, HitInfo&) (ray_tracing.cpp:202-213) for n rays: every triangle is tested, no
  * tree -- the reference's ground truth over all triangles (its BVH misses hits this loop finds: SURVEY.md F4).
  *   mesh >= 0: that mesh only (index into the scene's meshes); material_id stays -1, the loop never writes hitInfo.material.
