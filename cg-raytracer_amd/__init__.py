@@ -305,7 +305,9 @@ class Scene:
             lib().cgrt_scene_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self) -> None:
+        if lib is not None and C is not None:  # module globals are already gone when the interpreter is shutting down
+            self.close()
 
     # ---- certified walk (same results as the exact walk) ----
     def set_walk(self, certified: bool) -> None:
