@@ -45,13 +45,26 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def host_cpus():
+    """CPUs this process may actually use: the cgroup's quota when /sys/fs/cgroup/cpu.max states one (the GPU box shows 256
+    hardware threads and grants 16 CPUs), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sd, cam, W, H, budget_s=12.0):
     """The oracle (CPU restatement of the reference algorithm, kind "port") timed on this box's host cores on a bounded
     sample of the same frame: a centred block of rows, run as one `omp parallel for` over rows exactly like
     main.cpp:653-656, wall time by std::chrono like :791-797.  Two builds, as SURVEY.md section 8(d) asks: -O2 and -O0
     (the reference's de-facto build type, CMake sets none); each: one warm-up, then best of 3.  `value` is the -O2 figure."""
     orc = entry.load_oracle()
-    threads = os.cpu_count() or 1
+    threads = host_cpus()
     legs = {}
     sample = ""
     for o0 in (False, True):

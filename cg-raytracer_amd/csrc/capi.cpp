@@ -171,6 +171,8 @@ struct CgrtScene {
             void* p = nullptr;
             size_t cap = 0;
         } dev[3], pin[3];  // rays / hits / normals
+        void* bounce[2] = {nullptr, nullptr};  // pinned halves of the large-transfer pipeline (lane_upload / lane_download), made on first use
+        hipEvent_t bounce_ev[2] = {nullptr, nullptr};
         unsigned long long* d_counters = nullptr;
     };
     std::mutex lanes_mutex;
@@ -266,6 +268,10 @@ struct CgrtScene {
                 if (b.p) (void)hipFree(b.p);
             for (auto& b : L->pin)
                 if (b.p) (void)hipHostFree(b.p);
+            for (void* b : L->bounce)
+                if (b) (void)hipHostFree(b);
+            for (hipEvent_t e : L->bounce_ev)
+                if (e) (void)hipEventDestroy(e);
             if (L->d_counters) (void)hipFree(L->d_counters);
             if (L->stream) (void)hipStreamDestroy(L->stream);
             delete L;
@@ -740,11 +746,47 @@ struct LaneGuard {
         return hipSuccess;
     }
 };
-// Transfers below this size go through the lane's pinned staging buffers (a pageable hipMemcpyAsync of a few bytes costs
-// far more than copying them twice); larger ones are handed to the runtime directly.
-const size_t kStageBytes = 1u << 20;
+// large host copies on a few threads (one thread moves ~10 GB/s: a 1080p float frame would take as long as 8 device frames)
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const size_t chunk = 2u << 20;
+    if (bytes < 2 * chunk) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const unsigned nt = (unsigned)std::min<size_t>(4, bytes / chunk);
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++)
+        pool.emplace_back([=] {
+            const size_t b = bytes * t / nt, e = bytes * (t + 1) / nt;
+            std::memcpy(static_cast<char*>(dst) + b, static_cast<const char*>(src) + b, e - b);
+        });
+    std::memcpy(dst, src, bytes / nt);
+    for (std::thread& th : pool) th.join();
+}
 
-// host -> device on the lane's stream; `stage` = the pinned buffer to bounce through for small transfers
+// Transfers below this size go through the lane's pinned staging buffers (a pageable hipMemcpyAsync of a few bytes costs
+// far more than copying them twice).  Larger ones -- the lists of a host-driven wavefront, whole frames -- are cut into
+// kBounceBytes pieces that alternate between two pinned buffers: the host copies piece k+1 (on a few threads) while the DMA engine
+// moves piece k.  Handing the runtime a pageable pointer instead moved ~3 GB/s (66 MB of rays + 56 MB of hits and normals for a
+// 1080p list: 40-50 ms around a 0.3 ms kernel, profiles/r3_host_mirror.txt).
+const size_t kStageBytes = 1u << 20;
+const size_t kBounceBytes = 8u << 20;
+
+hipError_t lane_bounce(LaneGuard& g) {
+    for (int b = 0; b < 2; b++) {
+        if (!g.L->bounce[b]) {
+            const hipError_t e = hipHostMalloc(&g.L->bounce[b], kBounceBytes, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+        }
+        if (!g.L->bounce_ev[b]) {
+            const hipError_t e = hipEventCreateWithFlags(&g.L->bounce_ev[b], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+// host -> device on the lane's stream
 hipError_t lane_upload(LaneGuard& g, int k, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return hipSuccess;
     if (bytes <= kStageBytes) {
@@ -754,21 +796,70 @@ hipError_t lane_upload(LaneGuard& g, int k, void* dst, const void* src, size_t b
         std::memcpy(st, src, bytes);
         return hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, g.L->stream);
     }
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g.L->stream);
+    hipError_t e = lane_bounce(g);
+    if (e != hipSuccess) return e;
+    size_t piece = 0;
+    for (size_t off = 0; off < bytes; off += kBounceBytes, piece++) {
+        const int b = (int)(piece & 1);
+        const size_t m = std::min(kBounceBytes, bytes - off);
+        if (piece >= 2 && (e = hipEventSynchronize(g.L->bounce_ev[b])) != hipSuccess) return e;  // the DMA out of this half has finished
+        parallel_copy(g.L->bounce[b], static_cast<const char*>(src) + off, m);
+        if ((e = hipMemcpyAsync(static_cast<char*>(dst) + off, g.L->bounce[b], m, hipMemcpyHostToDevice, g.L->stream)) != hipSuccess) return e;
+        if ((e = hipEventRecord(g.L->bounce_ev[b], g.L->stream)) != hipSuccess) return e;
+    }
+    // the halves are reused by the next transfer of this call: it must not overwrite a piece still being read
+    for (int b = 0; b < 2; b++)
+        if ((e = hipEventSynchronize(g.L->bounce_ev[b])) != hipSuccess) return e;
+    return hipSuccess;
 }
-// device -> host: returns the pinned address to copy from after the stream has been synchronised (nullptr: the copy went
-// straight into dst)
-hipError_t lane_download(LaneGuard& g, int k, void* dst, const void* src, size_t bytes, void** staged) {
+// device -> host.  Small: returns the pinned address to copy from after the stream has been synchronised.  Large: the data is in
+// dst when the call returns (the stream's earlier work has been waited for), *staged stays null.  `keep` (optional, large path
+// only): one flag word per `stride` bytes -- elements whose word is zero are NOT written (normals of rays that missed).
+hipError_t lane_download(LaneGuard& g, int k, void* dst, const void* src, size_t bytes, void** staged, const CgrtHit* keep = nullptr,
+                         size_t stride = 0) {
     *staged = nullptr;
     if (bytes == 0) return hipSuccess;
-    if (bytes <= kStageBytes) {
+    if (bytes <= kStageBytes && !keep) {
         void* st = nullptr;
         const hipError_t e = g.pin(k, bytes, &st);
         if (e != hipSuccess) return e;
         *staged = st;
         return hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, g.L->stream);
     }
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g.L->stream);
+    hipError_t e = lane_bounce(g);
+    if (e != hipSuccess) return e;
+    const size_t piece_bytes = stride ? kBounceBytes / stride * stride : kBounceBytes;
+    const size_t npieces = (bytes + piece_bytes - 1) / piece_bytes;
+    for (size_t piece = 0; piece <= npieces; piece++) {
+        if (piece < npieces) {
+            const int b = (int)(piece & 1);
+            const size_t off = piece * piece_bytes, m = std::min(piece_bytes, bytes - off);
+            if ((e = hipMemcpyAsync(g.L->bounce[b], static_cast<const char*>(src) + off, m, hipMemcpyDeviceToHost, g.L->stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(g.L->bounce_ev[b], g.L->stream)) != hipSuccess) return e;
+        }
+        if (piece >= 1) {  // copy the previous piece out while this one is on the wire
+            const int b = (int)((piece - 1) & 1);
+            const size_t off = (piece - 1) * piece_bytes, m = std::min(piece_bytes, bytes - off);
+            if ((e = hipEventSynchronize(g.L->bounce_ev[b])) != hipSuccess) return e;
+            if (!keep) {
+                parallel_copy(static_cast<char*>(dst) + off, g.L->bounce[b], m);
+            } else {
+                const size_t first = off / stride, cnt = m / stride;
+                const unsigned nt = cnt >= 65536 ? 4 : 1;
+                auto part = [&](unsigned t) {
+                    const char* from = static_cast<const char*>(g.L->bounce[b]);
+                    char* to = static_cast<char*>(dst) + off;
+                    for (size_t i = cnt * t / nt, e2 = cnt * (t + 1) / nt; i < e2; i++)
+                        if (keep[first + i].hit) std::memcpy(to + i * stride, from + i * stride, stride);
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < nt; t++) pool.emplace_back(part, t);
+                part(0);
+                for (std::thread& th : pool) th.join();
+            }
+        }
+    }
+    return hipSuccess;
 }
 }  // namespace
 
@@ -996,16 +1087,20 @@ int cgrt_intersect_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtHit*
     HIP_TRY(g.dev(0, n * sizeof(CgrtRay), &dr));
     HIP_TRY(g.dev(1, n * sizeof(CgrtHit), &dh));
     HIP_TRY(lane_upload(g, 0, dr, rays, n * sizeof(CgrtRay)));
+    // HitInfo is left untouched on a miss (the kernels write a normal only with a hit): a short list starts from the caller's
+    // contents on the device; of a long one only the normals of rays that hit are copied back (lane_download's `keep`)
+    const bool big = n * sizeof(CgrtHit) > kStageBytes;
     if (normals) {
         HIP_TRY(g.dev(2, n * 12, &dn));
-        HIP_TRY(lane_upload(g, 2, dn, normals, n * 12));  // HitInfo is left untouched on a miss: start from the caller's contents
+        if (!big) HIP_TRY(lane_upload(g, 2, dn, normals, n * 12));
     }
     rc = cgrt_intersect_batch_device(s, static_cast<const CgrtRay*>(dr), n, static_cast<CgrtHit*>(dh), static_cast<float*>(dn), g.L->stream);
     if (rc) return rc;
     void *sh = nullptr, *sn = nullptr;
     HIP_TRY(lane_download(g, 1, hits, dh, n * sizeof(CgrtHit), &sh));
-    if (normals) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn));
-    HIP_TRY(hipStreamSynchronize(g.L->stream));  // this call's stream only: other streams and threads are not stalled
+    if (normals && !big) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn));
+    if (normals && big) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn, hits, 12));  // hits is complete here: only rays that hit
+    HIP_TRY(hipStreamSynchronize(g.L->stream));
     if (sh) std::memcpy(hits, sh, n * sizeof(CgrtHit));
     if (sn) std::memcpy(normals, sn, n * 12);
     return CGRT_OK;
@@ -1024,15 +1119,17 @@ int cgrt_intersect_brute_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, in
     HIP_TRY(g.dev(0, n * sizeof(CgrtRay), &dr));
     HIP_TRY(g.dev(1, n * sizeof(CgrtHit), &dh));
     HIP_TRY(lane_upload(g, 0, dr, rays, n * sizeof(CgrtRay)));
+    const bool big = n * sizeof(CgrtHit) > kStageBytes;  // as cgrt_intersect_batch
     if (normals) {
         HIP_TRY(g.dev(2, n * 12, &dn));
-        HIP_TRY(lane_upload(g, 2, dn, normals, n * 12));
+        if (!big) HIP_TRY(lane_upload(g, 2, dn, normals, n * 12));
     }
     HIP_TRY(launch_brute_batch(s->dev, static_cast<const float*>(dr), n, mesh < 0 ? -1 : mesh, static_cast<CgrtHitDev*>(dh), static_cast<float*>(dn),
                                g.L->stream));
     void *sh = nullptr, *sn = nullptr;
     HIP_TRY(lane_download(g, 1, hits, dh, n * sizeof(CgrtHit), &sh));
-    if (normals) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn));
+    if (normals && !big) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn));
+    if (normals && big) HIP_TRY(lane_download(g, 2, normals, dn, n * 12, &sn, hits, 12));  // hits is complete here: only rays that hit
     HIP_TRY(hipStreamSynchronize(g.L->stream));
     if (sh) std::memcpy(hits, sh, n * sizeof(CgrtHit));
     if (sn) std::memcpy(normals, sn, n * 12);
@@ -1082,15 +1179,18 @@ int cgrt_trace_primary(CgrtScene* s, const CgrtCamera* cam, int W, int H, int x0
     // pixels outside the traced tiles keep caller data: seed the device frame with it -- unless this call writes every pixel
     const bool whole_frame = (x0 == 0 && y0 == 0 && x1 == W && y1 == H && nranks == 1);
     if (!whole_frame) HIP_TRY(lane_upload(g, 1, dh, hits, npix * sizeof(CgrtHit)));
+    // normals of pixels that miss keep the caller's contents: seeded on the device, or -- a large whole frame, whose hit flags all
+    // come from this call -- only the normals of pixels that hit are copied back
+    const bool keep_by_hit = whole_frame && npix * sizeof(CgrtHit) > kStageBytes;
     if (normals) {
         HIP_TRY(g.dev(2, npix * 12, &dn));
-        HIP_TRY(lane_upload(g, 2, dn, normals, npix * 12));
+        if (!keep_by_hit) HIP_TRY(lane_upload(g, 2, dn, normals, npix * 12));
     }
     rc = cgrt_trace_primary_device(s, cam, W, H, x0, y0, x1, y1, rank, nranks, static_cast<CgrtHit*>(dh), static_cast<float*>(dn), g.L->stream);
     if (rc) return rc;
     void *sh = nullptr, *sn = nullptr;
     HIP_TRY(lane_download(g, 1, hits, dh, npix * sizeof(CgrtHit), &sh));
-    if (normals) HIP_TRY(lane_download(g, 2, normals, dn, npix * 12, &sn));
+    if (normals) HIP_TRY(lane_download(g, 2, normals, dn, npix * 12, &sn, keep_by_hit ? hits : nullptr, 12));
     HIP_TRY(hipStreamSynchronize(g.L->stream));
     if (sh) std::memcpy(hits, sh, npix * sizeof(CgrtHit));
     if (sn) std::memcpy(normals, sn, npix * 12);
@@ -1190,25 +1290,6 @@ int cgrt_count_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, CgrtCounters
 // renderRayTracing / getFinalColor (src/main.cpp:298-310, :648-720) as a device wavefront
 // counted (optional, 3 blocks): the frame is rendered with the instrumented kernels (never timed) and the work of its primary,
 // shadow and mirror traversals is returned separately
-namespace {
-// large host copies on a few threads (one thread moves ~10 GB/s: a 1080p float frame would take as long as 8 device frames)
-void parallel_copy(void* dst, const void* src, size_t bytes) {
-    const size_t chunk = 4u << 20;
-    if (bytes < 2 * chunk) {
-        std::memcpy(dst, src, bytes);
-        return;
-    }
-    const unsigned nt = (unsigned)std::min<size_t>(4, bytes / chunk);
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; t++)
-        pool.emplace_back([=] {
-            const size_t b = bytes * t / nt, e = bytes * (t + 1) / nt;
-            std::memcpy(static_cast<char*>(dst) + b, static_cast<const char*>(src) + b, e - b);
-        });
-    std::memcpy(dst, src, bytes / nt);
-    for (std::thread& th : pool) th.join();
-}
-}  // namespace
 
 // rgb (optional): the caller's frame; mapped (optional): receives the scene's pinned staging frame (valid until the next
 // cgrt_render* call on this scene).  With nranks > 1 only the pixels this rank owns are meaningful in the staging frame, and only

@@ -57,3 +57,5 @@ RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const 
 // Same, into a plain W*H rgb float buffer indexed y*W+x (not flipped).
 RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb, int maxLevel = 2,
                            const SoftShadowSampler* sampler = nullptr);
+// renderToBuffer keeps its per-level arrays (up to 1 GiB) for the next frame; this hands them back to the C library.
+void releaseRenderBuffers();

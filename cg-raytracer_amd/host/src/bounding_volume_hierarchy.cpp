@@ -3,10 +3,12 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 
 #include "../../../include/cgrt.h"
+#include "host_threads.h"
 
 namespace {
 int host_device() {
@@ -49,19 +51,27 @@ int BoundingVolumeHierarchy::numLevels() const { return cgrt_num_levels(m_handle
 void BoundingVolumeHierarchy::intersectBatch(Ray* rays, HitInfo* hitInfos, uint8_t* hit, size_t n, uint32_t* primIds) const {
     if (n == 0) return;
     static_assert(sizeof(Ray) == sizeof(CgrtRay), "Ray == CgrtRay");
-    std::vector<CgrtHit> hits(n);
-    std::vector<float> normals(3 * n);
-    for (size_t i = 0; i < n; i++) {  // HitInfo is left untouched on a miss: seed with the caller's contents
-        normals[3 * i] = hitInfos[i].normal.x;
-        normals[3 * i + 1] = hitInfos[i].normal.y;
-        normals[3 * i + 2] = hitInfos[i].normal.z;
+    // HitInfo is left untouched on a miss: normal and material are taken over only where the ray hit.  A handful of rays (the
+    // per-ray call sites: one) stays on the stack; the loops over a wavefront's list run on the host's cores.
+    constexpr size_t SMALL = 64;
+    CgrtHit hits_small[SMALL];
+    float normals_small[3 * SMALL];
+    std::unique_ptr<CgrtHit[]> hits_big;
+    std::unique_ptr<float[]> normals_big;
+    CgrtHit* hits = hits_small;
+    float* normals = normals_small;
+    if (n > SMALL) {
+        hits_big.reset(new CgrtHit[n]);  // not value-initialised: the call writes every hit, and the normals are read only with a hit
+        normals_big.reset(new float[3 * n]);
+        hits = hits_big.get();
+        normals = normals_big.get();
     }
-    if (cgrt_intersect_batch(m_handle.get(), reinterpret_cast<const CgrtRay*>(rays), n, hits.data(), normals.data()) != CGRT_OK)
-        fail("cgrt_intersect_batch");
+    if (cgrt_intersect_batch(m_handle.get(), reinterpret_cast<const CgrtRay*>(rays), n, hits, normals) != CGRT_OK) fail("cgrt_intersect_batch");
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam()) if (n > 16384)
     for (size_t i = 0; i < n; i++) {
         rays[i].t = hits[i].t;
         hit[i] = (uint8_t)hits[i].hit;
-        hitInfos[i].normal = cgrt::vec3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+        if (hits[i].hit) hitInfos[i].normal = cgrt::vec3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
         if (hits[i].material_id >= 0) hitInfos[i].material = m_materials[hits[i].material_id];  // bvh.cpp:547
         if (primIds) primIds[i] = hits[i].prim_id;
     }
@@ -75,10 +85,11 @@ bool BoundingVolumeHierarchy::intersect(Ray& ray, HitInfo& hitInfo) const {
 
 void BoundingVolumeHierarchy::tracePrimary(const CgrtCamera& cam, int W, int H, Ray* rays, HitInfo* hitInfos, uint8_t* hit) const {
     const size_t n = (size_t)W * H;
-    std::vector<CgrtHit> hits(n);
-    std::vector<float> normals(3 * n, 0.0f);
-    if (cgrt_trace_primary(m_handle.get(), &cam, W, H, 0, 0, W, H, 0, 1, hits.data(), normals.data()) != CGRT_OK) fail("cgrt_trace_primary");
+    std::unique_ptr<CgrtHit[]> hits(new CgrtHit[n]);
+    std::unique_ptr<float[]> normals(new float[3 * n]);
+    if (cgrt_trace_primary(m_handle.get(), &cam, W, H, 0, 0, W, H, 0, 1, hits.get(), normals.get()) != CGRT_OK) fail("cgrt_trace_primary");
     if (cgrt_generate_rays(m_handle.get(), &cam, W, H, 0, 0, W, H, reinterpret_cast<CgrtRay*>(rays)) != CGRT_OK) fail("cgrt_generate_rays");
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam()) if (n > 16384)
     for (size_t i = 0; i < n; i++) {
         rays[i].t = hits[i].t;
         hit[i] = (uint8_t)hits[i].hit;

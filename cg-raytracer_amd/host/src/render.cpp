@@ -5,13 +5,20 @@
 
 #include <omp.h>
 
+#include "host_threads.h"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
+#include <mutex>
+#include <new>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <vector>
 
 namespace {
 using cgrt::vec3;
@@ -75,6 +82,128 @@ const cgrt::vec3& SoftShadowSampler::draw(uint32_t pixel, uint32_t level, uint32
     return units[h % (uint32_t)units.size()];
 }
 
+namespace {
+// The driver's large arrays come from a cache of blocks that survives the call: a level of a 1080p frame holds ~300 MB of rays,
+// HitInfos and items, and handing them back to the C library means munmap + fresh page faults on every frame (measured: 35 of
+// the 60 ms of a Cornell frame).  Best fit with at most 50 % slack; at most kCacheLimit bytes are kept (oldest blocks go first);
+// releaseRenderBuffers() empties it.
+class BlockCache {
+public:
+    static constexpr size_t kCacheLimit = size_t(1) << 30, kSmall = size_t(1) << 16;
+    void* take(size_t need, size_t& cap) {
+        if (need >= kSmall) {
+            std::lock_guard<std::mutex> lk(m_);
+            size_t best = blocks_.size();
+            for (size_t i = 0; i < blocks_.size(); i++)
+                if (blocks_[i].cap >= need && blocks_[i].cap <= need + need / 2 && (best == blocks_.size() || blocks_[i].cap < blocks_[best].cap)) best = i;
+            if (best != blocks_.size()) {
+                void* p = blocks_[best].p;
+                cap = blocks_[best].cap;
+                bytes_ -= cap;
+                blocks_.erase(blocks_.begin() + (std::ptrdiff_t)best);
+                return p;
+            }
+        }
+        cap = need;
+        void* p = std::malloc(need);
+        if (!p) throw std::bad_alloc();
+        return p;
+    }
+    void give(void* p, size_t cap) {
+        if (cap < kSmall || cap > kCacheLimit) {
+            std::free(p);
+            return;
+        }
+        std::lock_guard<std::mutex> lk(m_);
+        while (!blocks_.empty() && bytes_ + cap > kCacheLimit) {
+            std::free(blocks_.front().p);
+            bytes_ -= blocks_.front().cap;
+            blocks_.erase(blocks_.begin());
+        }
+        blocks_.push_back({p, cap});
+        bytes_ += cap;
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lk(m_);
+        for (Block& b : blocks_) std::free(b.p);
+        blocks_.clear();
+        bytes_ = 0;
+    }
+    ~BlockCache() { clear(); }
+
+private:
+    struct Block {
+        void* p;
+        size_t cap;
+    };
+    std::mutex m_;
+    std::vector<Block> blocks_;
+    size_t bytes_ = 0;
+};
+BlockCache g_blocks;
+
+// An array whose elements the driver's parallel loops write before anything reads them: not value-initialised (a
+// std::vector would touch a level's rays and HitInfos on one thread first).
+template <class T>
+struct Array {
+    static_assert(std::is_trivially_copyable<T>::value && std::is_trivially_destructible<T>::value, "plain data only");
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    Array() = default;
+    explicit Array(size_t count) : n(count) {
+        if (count) p = static_cast<T*>(g_blocks.take(count * sizeof(T), cap));
+    }
+    Array(Array&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr, o.n = o.cap = 0; }
+    Array& operator=(Array&& o) noexcept {
+        if (this != &o) {
+            if (p) g_blocks.give(p, cap);
+            p = o.p, n = o.n, cap = o.cap;
+            o.p = nullptr, o.n = o.cap = 0;
+        }
+        return *this;
+    }
+    Array(const Array&) = delete;
+    Array& operator=(const Array&) = delete;
+    ~Array() {
+        if (p) g_blocks.give(p, cap);
+    }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* data() { return p; }
+};
+
+// off[i] = number of set flags before i; returns their total.  The lists of a level keep the order a sequential loop over the
+// items would give them, whichever thread writes an entry.
+size_t scanFlags(const uint8_t* flag, size_t n, uint32_t* off) {
+    std::vector<size_t> part((size_t)cgrt::hostTeam() + 1, 0);
+#pragma omp parallel num_threads(cgrt::hostTeam())
+    {
+        const size_t T = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+        const size_t b = n * t / T, e = n * (t + 1) / T;
+        size_t c = 0;
+        for (size_t i = b; i < e; i++) c += flag[i] != 0;
+        part[t + 1] = c;
+#pragma omp barrier
+#pragma omp single
+        for (size_t k = 0; k < T; k++) part[k + 1] += part[k];
+        size_t o = part[t];
+        for (size_t i = b; i < e; i++) {
+            off[i] = (uint32_t)o;
+            o += flag[i] != 0;
+        }
+    }
+    size_t total = 0;
+    for (size_t v : part) total = std::max(total, v);
+    return total;
+}
+}  // namespace
+
+void releaseRenderBuffers() { g_blocks.clear(); }
+
+// The loops over a level's items are `omp parallel for`s, as the reference's loop over rows is (main.cpp:653-656): every item writes
+// only its own entries, and list positions come from prefix sums, so the frame does not depend on the thread count.
 RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, int W, int H, float* rgb,
                            int maxLevel, const SoftShadowSampler* sampler) {
     RenderStats st;
@@ -86,42 +215,51 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
     const auto t_begin = Clock::now();
     const size_t npix = (size_t)W * H;
     const float eps = 0.001;  // main.cpp:110, :255
-    std::vector<Ray> rays(npix);
-    std::vector<HitInfo> his(npix);
-    std::vector<uint8_t> hit(npix, 0);
-    std::vector<uint32_t> parent(npix), pixel(npix);
-    for (size_t i = 0; i < npix; i++) parent[i] = pixel[i] = (uint32_t)i;
-    std::vector<std::vector<LevelItem>> levels;
+    const HitInfo noHit{};
+    Array<Ray> rays(npix);
+    Array<HitInfo> his(npix);
+    Array<uint8_t> hit(npix);
+    Array<uint32_t> parent(npix), pixel(npix);
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
+    for (size_t i = 0; i < npix; i++) {
+        parent[i] = pixel[i] = (uint32_t)i;
+        his[i] = noHit;
+        hit[i] = 0;
+    }
+    std::vector<Array<LevelItem>> levels;
     if (maxLevel >= 1) {  // trace(0): `level >= maxLevel` -> black without tracing (main.cpp:267)
         auto t0 = Clock::now();
         bvh.tracePrimary(camera.abi(), W, H, rays.data(), his.data(), hit.data());
         st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
         st.primary = npix;
     }
-    for (int level = 0; level < maxLevel && !rays.empty(); level++) {
-        const size_t n = rays.size();
+    size_t n = npix;
+    for (int level = 0; level < maxLevel && n; level++) {
         const size_t L = scene.pointLights.size();
-        std::vector<LevelItem> items(n);
+        Array<LevelItem> items(n);
+        Array<uint32_t> hoff(n);  // hits before item i
+        const size_t nh = scanFlags(hit.data(), n, hoff.data());
         // ---- shadow rays of every hit x light (pointInShadow, main.cpp:104-135) ----
-        std::vector<Ray> srays;
-        std::vector<uint32_t> sowner;
-        std::vector<float> sdist;
-        srays.reserve(n * L);
+        Array<Ray> srays(nh * L);
+        Array<float> sdist(nh * L);
+        Array<HitInfo> shi(nh * L);
+        Array<uint8_t> shit(nh * L);
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
         for (size_t i = 0; i < n; i++) {
             if (!hit[i]) continue;
             const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
             for (size_t l = 0; l < L; l++) {
+                const size_t q = (size_t)hoff[i] * L + l;
                 const vec3 fromPosToLight = scene.pointLights[l].position - pointOn;
                 Ray r{pointOn, cgrt::normalize(fromPosToLight), std::numeric_limits<float>::max()};
                 r.origin = r.origin + eps * r.direction;
-                srays.push_back(r);
-                sowner.push_back((uint32_t)i);
-                sdist.push_back(cgrt::length(fromPosToLight));
+                srays[q] = r;
+                sdist[q] = cgrt::length(fromPosToLight);
+                shi[q] = noHit;
+                shit[q] = 0;
             }
         }
-        std::vector<HitInfo> shi(srays.size());
-        std::vector<uint8_t> shit(srays.size(), 0);
-        {
+        if (nh && L) {
             auto t0 = Clock::now();
             bvh.intersectBatch(srays.data(), shi.data(), shit.data(), srays.size());
             st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
@@ -133,47 +271,53 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
         if (SL) {
             const uint32_t S = sampler->samples;
             const size_t chunkItems = std::max<size_t>(1, (size_t(1) << 22) / (SL * S));  // ~4 M rays per batch
-            std::vector<Ray> qr;
-            std::vector<float> lightT;
-            std::vector<uint32_t> slot;
-            std::vector<HitInfo> qh;
-            std::vector<uint8_t> qhit;
             for (size_t i0 = 0; i0 < n; i0 += chunkItems) {
                 const size_t i1 = std::min(n, i0 + chunkItems);
-                qr.clear();
-                lightT.clear();
-                slot.clear();
+                const size_t h0 = hoff[i0], h1 = i1 < n ? (size_t)hoff[i1] : nh;
+                const size_t nq = (h1 - h0) * SL * S;
+                if (!nq) continue;
+                Array<Ray> qr(nq);
+                Array<float> lightT(nq);
+                Array<HitInfo> qh(nq);
+                Array<uint8_t> qhit(nq);
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
                 for (size_t i = i0; i < i1; i++) {
                     if (!hit[i]) continue;
                     const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
                     for (size_t l = 0; l < SL; l++) {
                         const SphericalLight& spherical = scene.sphericalLight[l];
                         for (uint32_t k = 0; k < S; k++) {
+                            const size_t q = (((size_t)hoff[i] - h0) * SL + l) * S + k;
                             const vec3 randomPointOnSphere = spherical.position + spherical.radius * sampler->draw(pixel[i], (uint32_t)level, (uint32_t)l, k);
                             Ray newRay;  // :178, members in declaration order
                             newRay.origin = pointOn + (float)(0.001) * cgrt::normalize(randomPointOnSphere - pointOn);
                             newRay.direction = cgrt::normalize(randomPointOnSphere - pointOn);
                             newRay.t = cgrt::length(newRay.origin - randomPointOnSphere);
-                            qr.push_back(newRay);
-                            lightT.push_back(cgrt::length(newRay.origin - randomPointOnSphere));
-                            slot.push_back((uint32_t)(i * SL + l));
+                            qr[q] = newRay;
+                            lightT[q] = cgrt::length(newRay.origin - randomPointOnSphere);
+                            qh[q] = noHit;
+                            qhit[q] = 0;
                         }
                     }
                 }
-                qh.assign(qr.size(), HitInfo{});
-                qhit.assign(qr.size(), 0);
                 auto t0 = Clock::now();
                 bvh.intersectBatch(qr.data(), qh.data(), qhit.data(), qr.size());
                 st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
                 st.softShadow += qr.size();
-                for (size_t q = 0; q < qr.size(); q++)
-                    if (!qhit[q] || qr[q].t > lightT[q]) litCount[slot[q]]++;  // :183-199
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
+                for (size_t i = i0; i < i1; i++) {
+                    if (!hit[i]) continue;
+                    for (size_t l = 0; l < SL; l++)
+                        for (uint32_t k = 0; k < S; k++) {
+                            const size_t q = (((size_t)hoff[i] - h0) * SL + l) * S + k;
+                            if (!qhit[q] || qr[q].t > lightT[q]) litCount[i * SL + l]++;  // :183-199
+                        }
+                }
             }
         }
-        // ---- direct light (shading, main.cpp:219-232) + reflection rays (shade, :241-264) ----
-        std::vector<Ray> nrays;
-        std::vector<uint32_t> nparent, npixel;
-        size_t s = 0;
+        // ---- direct light (shading, main.cpp:219-232); which items spawn a reflection ray (shade, :241-264) ----
+        Array<uint8_t> spawns(n);
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
         for (size_t i = 0; i < n; i++) {
             LevelItem& it = items[i];
             it.hit = hit[i] != 0;
@@ -181,6 +325,7 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
             it.parent = parent[i];
             it.direct = vec3(0.0f);
             it.ks = vec3(0.0f);
+            spawns[i] = 0;
             if (!it.hit) continue;
             const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
             vec3 result(0.0f);
@@ -194,10 +339,11 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
                 result += diffuse * softShadowCounter;
                 result += specular * softShadowCounter;
             }
-            for (size_t l = 0; l < L; l++, s++) {
+            for (size_t l = 0; l < L; l++) {
+                const size_t q = (size_t)hoff[i] * L + l;
                 const PointLight& light = scene.pointLights[l];
                 const vec3 fromPosToLight = cgrt::normalize(light.position - pointOn);
-                const bool inShadow = shit[s] && !(srays[s].t + eps >= sdist[s]);  // :118-130
+                const bool inShadow = shit[q] && !(srays[q].t + eps >= sdist[q]);  // :118-130
                 if (inShadow) continue;
                 result += diffuseOneLight(light, fromPosToLight, his[i]);
                 result += specularOneLight(rays[i], light, fromPosToLight, his[i]);
@@ -206,32 +352,50 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
             it.ks = his[i].material.ks;
             if (his[i].material.ks.z <= 0.01f) continue;  // :246: the comma operator leaves only ks.z tested
             if (level + 1 >= maxLevel) continue;          // trace(level+1) would return black (:267): color = direct + 0 * ks
+            spawns[i] = 1;
+        }
+        // ---- the reflection rays, in item order ----
+        Array<uint32_t> roff(n);
+        const size_t nr = scanFlags(spawns.data(), n, roff.data());
+        Array<Ray> nrays(nr);
+        Array<uint32_t> nparent(nr), npixel(nr);
+        Array<HitInfo> nhis(nr);
+        Array<uint8_t> nhit(nr);
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
+        for (size_t i = 0; i < n; i++) {
+            if (!spawns[i]) continue;
+            const size_t c = roff[i];
+            const vec3 pointOn = rays[i].origin + rays[i].direction * rays[i].t;
             const vec3 reflected = cgrt::normalize(cgrt::reflect(rays[i].direction, his[i].normal));
             Ray rr{pointOn, reflected, cgrt::length(rays[i].direction)};  // :254: t = |direction|, not FLT_MAX
             rr.origin = rr.origin + eps * rr.direction;
-            it.child = (int)nrays.size();
-            nrays.push_back(rr);
-            nparent.push_back((uint32_t)i);
-            npixel.push_back(pixel[i]);
+            items[i].child = (int)c;
+            nrays[c] = rr;
+            nparent[c] = (uint32_t)i;
+            npixel[c] = pixel[i];
+            nhis[c] = noHit;
+            nhit[c] = 0;
         }
         levels.push_back(std::move(items));
         rays = std::move(nrays);
         parent = std::move(nparent);
         pixel = std::move(npixel);
-        his.assign(rays.size(), HitInfo{});
-        hit.assign(rays.size(), 0);
-        if (!rays.empty()) {
+        his = std::move(nhis);
+        hit = std::move(nhit);
+        n = nr;
+        if (n) {
             auto t0 = Clock::now();
-            bvh.intersectBatch(rays.data(), his.data(), hit.data(), rays.size());
+            bvh.intersectBatch(rays.data(), his.data(), hit.data(), n);
             st.seconds_device += std::chrono::duration<double>(Clock::now() - t0).count();
-            st.reflection += rays.size();
+            st.reflection += n;
         }
     }
     // ---- backward pass: color = directColor + reflectedColor * ks (main.cpp:262), deepest level first ----
-    std::vector<vec3> below;
+    Array<vec3> below;
     for (int level = (int)levels.size() - 1; level >= 0; level--) {
-        const std::vector<LevelItem>& items = levels[level];
-        std::vector<vec3> color(items.size());
+        const Array<LevelItem>& items = levels[level];
+        Array<vec3> color(items.size());
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
         for (size_t i = 0; i < items.size(); i++) {
             const LevelItem& it = items[i];
             if (!it.hit)
@@ -243,6 +407,7 @@ RenderStats renderToBuffer(const Scene& scene, const Trackball& camera, const Bo
         }
         below = std::move(color);
     }
+#pragma omp parallel for schedule(static) num_threads(cgrt::hostTeam())
     for (size_t i = 0; i < npix; i++) {
         const vec3 c = levels.empty() ? vec3(0.0f) : below[i];
         rgb[3 * i] = c.x;
@@ -449,7 +614,7 @@ RenderStats renderRayTracingPerRay(const Scene& scene, const Trackball& camera, 
 RenderStats renderRayTracing(const Scene& scene, const Trackball& camera, const BoundingVolumeHierarchy& bvh, Screen& screen, int maxLevel,
                              const SoftShadowSampler* sampler) {
     const int W = screen.width(), H = screen.height();
-    std::vector<float> rgb((size_t)W * H * 3);
+    Array<float> rgb((size_t)W * H * 3);
     RenderStats st = renderToBuffer(scene, camera, bvh, W, H, rgb.data(), maxLevel, sampler);
     screen.setFrame(rgb.data());  // main.cpp:696 for every pixel
     return st;

@@ -10,13 +10,16 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 
+import bench
+
 pkg = e.load_package()
 orc = e.load_oracle()
+CPUS = bench.host_cpus()  # the cgroup's CPU quota (16 on the GPU box, which shows 256 hardware threads)
 sd = pkg.scenes.SceneData.load(os.path.join(e.ROOT, "tests", "golden", "scenes", "monkey.npz"))
 W = H = 800
 cam = pkg.scenes.default_camera(W, H)
 rays = orc.generate_rays(cam, W, H)
-print(f"host cores: {os.cpu_count()}; scene monkey-rotated.obj ({sd.ntris} triangles), {W}x{H}")
+print(f"host: {os.cpu_count()} hardware threads, {CPUS} usable (cgroup quota); scene monkey-rotated.obj ({sd.ntris} triangles), {W}x{H}")
 QUICK = os.environ.get("PER_RAY_QUICK") == "1"  # only the call-rate table with combining on
 for combining in ((True,) if QUICK else (False, True)):
     pkg.set_call_combining(combining)
@@ -32,13 +35,13 @@ if QUICK:
     sys.exit(0)
 o2 = orc.OracleScene(sd)
 t0 = time.time()
-ref, nrays = o2.render(cam, W, H, sd.point_lights, max_level=2)
+ref, nrays = o2.render(cam, W, H, sd.point_lights, max_level=2, threads=CPUS)
 t_o2 = time.time() - t0
 o0 = orc.OracleScene(sd, o0=True)
 t0 = time.time()
-o0.render(cam, W, H, sd.point_lights, max_level=2)
+o0.render(cam, W, H, sd.point_lights, max_level=2, threads=CPUS)
 t_o0 = time.time() - t0
-print(f"frame {W}x{H} depth 2 = {nrays} rays: CPU oracle (recursive per-pixel driver, {os.cpu_count()} threads) -O2 {t_o2 * 1e3:.0f} ms, -O0 {t_o0 * 1e3:.0f} ms "
+print(f"frame {W}x{H} depth 2 = {nrays} rays: CPU oracle (recursive per-pixel driver, {CPUS} threads) -O2 {t_o2 * 1e3:.0f} ms, -O0 {t_o0 * 1e3:.0f} ms "
       f"(BASELINE.md: the report's monkey frame 0.5 s on unstated hardware)")
 for T in (8, 64, 256):
     rgb, st = pkg.host_render_per_ray(sd, cam, W, H, 2, threads=T)
