@@ -4,6 +4,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <linux/futex.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -185,10 +190,11 @@ struct CgrtScene {
     // publishes the results; the other callers wait on the generation's state and copy their own hits out.  While a generation
     // is on the GPU the next one fills up, so the batch size adapts to the load.  Nothing stays resident on the device.
 #ifndef CGRT_COMBINE_RINGS
-#define CGRT_COMBINE_RINGS 2  // generations that can be open / in flight at a time (4 measured no better: profiles/r3_per_ray.txt)
+#define CGRT_COMBINE_RINGS 16  // most generations that can be open / in flight at a time; `nrings` of them are used
 #endif
     struct Combiner {
         static const int NRINGS = CGRT_COMBINE_RINGS;
+        int nrings = 8;  // set before the rings are made (combined_intersect; CGRT_COMBINE_NRINGS)
         static const uint32_t CAP = 32768;       // ray slots per ring
         static const uint32_t MAX_N = 64;        // calls with more rays than this take the direct path
         static const int MAX_CALLERS = 256;      // callers inside the entry at a time (more take the direct path)
@@ -222,6 +228,11 @@ struct CgrtScene {
             std::string err;
         } ring[CGRT_COMBINE_RINGS];
         std::mutex init_mu;
+        // Callers that SLEEP (futex) instead of spinning -- taken when more callers are inside than the process has CPUs (see
+        // combined_intersect): `epoch` counts rings set free (what callers without a ring wait for), the sleeper counts tell the
+        // thread that publishes whether a wake-up call is needed at all.
+        alignas(64) std::atomic<uint32_t> epoch{0};
+        std::atomic<int> epoch_sleepers{0}, done_sleepers{0};
         alignas(64) std::atomic<int> inside{0};   // callers currently inside the combining entry
         alignas(64) std::atomic<int> ready{0};    // 0 = rings not allocated yet, 1 = usable, -1 = allocation failed (direct path for good)
         // diagnostics (cgrt_debug_combiner_stats): generations launched, rays in them, the largest generation, nanoseconds the
@@ -873,6 +884,27 @@ int cgrt_intersect_batch_device(CgrtScene* s, const CgrtRay* d_rays, uint64_t n,
 }
 
 namespace {
+// CPUs this process may use: the affinity mask, cut to the cgroup's quota when /sys/fs/cgroup/cpu.max states one (a container that
+// shows 256 hardware threads and grants 16 CPUs throttles a process whose 64 threads all spin).
+int usable_cpus() {
+    static const int n = [] {
+        cpu_set_t set;
+        int c = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) c = std::min<long long>(c, (quota + period - 1) / period);
+            std::fclose(f);
+        }
+        return std::max(1, c);
+    }();
+    return n;
+}
+inline void futex_wait(std::atomic<uint32_t>& word, uint32_t expected) {  // returns at once when the word no longer holds `expected`
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake_all(std::atomic<uint32_t>& word) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
 inline void cpu_relax(unsigned& spins) {  // a wait of a few microseconds is the common case: spin first, then give the core away
     if (++spins < 4096)
         __builtin_ia32_pause();
@@ -890,7 +922,9 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         rdy = cb.ready.load(std::memory_order_acquire);
         if (rdy == 0) {
             bool ok = hipSetDevice(s->device) == hipSuccess;
-            for (auto& r : cb.ring) {
+            if (const char* e = getenv("CGRT_COMBINE_NRINGS")) cb.nrings = std::max(1, std::min(atoi(e), (int)C::NRINGS));
+            for (int k = 0; k < cb.nrings; k++) {
+                C::Ring& r = cb.ring[k];
                 if (!ok) break;
                 hipError_t e = hipHostMalloc(&r.host, total + 64, hipHostMallocMapped);  // (+ the completion word)
                 if (e == hipSuccess) std::memset(static_cast<char*>(r.host) + total, 0, 64);
@@ -910,14 +944,29 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         ~Inside() { c.fetch_sub(1, std::memory_order_relaxed); }
     } inside(cb.inside);
     if (inside.before >= C::MAX_CALLERS) return 0;  // (the bound the word's bit fields and JOIN_MAX rely on)
+    // How a caller waits.  With a CPU for every caller, spinning is the fastest hand-over (8 callers: 0.45 M calls/s).  With more
+    // callers than CPUs the spinners take the CPUs from the callers that have work to do -- and inside a CPU quota they get the
+    // whole process throttled -- so then a caller spins for a moment only and sleeps on a futex; whoever publishes what the
+    // sleepers wait for wakes them.  CGRT_COMBINE_SLEEP=0 / 1 forces one or the other.
+    static const int sleep_env = [] {
+        const char* e = getenv("CGRT_COMBINE_SLEEP");
+        return e ? atoi(e) : -1;
+    }();
+    const bool sleepy = sleep_env >= 0 ? sleep_env != 0 : inside.before + 1 > usable_cpus();
+    static const unsigned spin_first = [] {  // pauses before a sleepy caller goes to sleep (a few microseconds)
+        const char* e = getenv("CGRT_COMBINE_SPIN");
+        return e ? (unsigned)atoi(e) : 20u;
+    }();
     // ---- join the open generation, or open a free ring (and lead it) ----
+    const int NR = cb.nrings;
     int b = -1;
     uint32_t at = 0;
     uint32_t gen = 0;
     bool leader = false;
     unsigned spins = 0;
     while (b < 0) {
-        for (int k = 0; k < C::NRINGS && b < 0; k++) {
+        const uint32_t epoch = cb.epoch.load(std::memory_order_seq_cst);  // (read BEFORE the rings are looked at)
+        for (int k = 0; k < NR && b < 0; k++) {
             C::Ring& r = cb.ring[k];
             const uint64_t seen = r.word.load(std::memory_order_acquire);
             if (C::st_of(seen) != C::OPEN || C::count_of(seen) > C::JOIN_MAX) continue;
@@ -928,7 +977,7 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
                 gen = (uint32_t)(w >> 32);
             }  // else: closed in between -- the stray counts are harmless (see Combiner)
         }
-        for (int k = 0; k < C::NRINGS && b < 0; k++) {
+        for (int k = 0; k < NR && b < 0; k++) {
             C::Ring& r = cb.ring[k];
             uint64_t w = r.word.load(std::memory_order_acquire);
             if (C::st_of(w) != C::FREE) continue;
@@ -940,7 +989,19 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
                 leader = true;
             }
         }
-        if (b < 0) cpu_relax(spins);  // both rings are on the GPU or being read out: the next generation opens in a moment
+        if (b >= 0) break;
+        // both rings are on the GPU or being read out: the next generation opens in a moment
+        if (sleepy && ++spins > spin_first) {
+            bool open = false;  // an OPEN ring that is merely full does not announce itself: keep polling while there is one
+            for (int k = 0; k < NR; k++) open |= C::st_of(cb.ring[k].word.load(std::memory_order_relaxed)) == C::OPEN;
+            if (!open) {
+                cb.epoch_sleepers.fetch_add(1, std::memory_order_seq_cst);
+                futex_wait(cb.epoch, epoch);  // until a ring has been set free since `epoch` was read
+                cb.epoch_sleepers.fetch_sub(1, std::memory_order_relaxed);
+                continue;
+            }
+        }
+        cpu_relax(spins);
     }
     C::Ring& r = cb.ring[b];
     std::memcpy(static_cast<char*>(r.host) + sizeof(CgrtRay) * (size_t)at, rays, sizeof(CgrtRay) * (size_t)n);
@@ -951,7 +1012,7 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         uint32_t last = 0, quiet = 0;
         for (unsigned k = 0; k < 1000; k++) {
             int parked = 0;
-            for (int k = 0; k < C::NRINGS; k++) {
+            for (int k = 0; k < NR; k++) {
                 if (k == b) continue;
                 const uint64_t ow = cb.ring[k].word.load(std::memory_order_relaxed);
                 if (C::st_of(ow) == C::RUNNING || C::st_of(ow) == C::DONE) parked += (int)cb.ring[k].readers.load(std::memory_order_relaxed);
@@ -1029,10 +1090,21 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
         cb.ns_gpu.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_closed).count(),
                             std::memory_order_relaxed);
         r.word.store(C::pack(C::DONE, joined, cnt, gen), std::memory_order_release);
-        r.done_gen.store(gen + 1u, std::memory_order_release);
+        r.done_gen.store(gen + 1u, std::memory_order_seq_cst);
+        if (cb.done_sleepers.load(std::memory_order_seq_cst) > 0) futex_wake_all(r.done_gen);
     } else {
         unsigned sp = 0;
-        while ((int32_t)(r.done_gen.load(std::memory_order_acquire) - gen) <= 0) cpu_relax(sp);
+        for (;;) {
+            const uint32_t dg = r.done_gen.load(std::memory_order_seq_cst);
+            if ((int32_t)(dg - gen) > 0) break;
+            if (sleepy && ++sp > spin_first) {
+                cb.done_sleepers.fetch_add(1, std::memory_order_seq_cst);
+                futex_wait(r.done_gen, dg);  // (returns at once if the leader has published in between)
+                cb.done_sleepers.fetch_sub(1, std::memory_order_relaxed);
+            } else {
+                cpu_relax(sp);
+            }
+        }
     }
     rc_out = r.rc;
     if (r.rc == CGRT_OK) {
@@ -1048,6 +1120,8 @@ int combined_intersect(CgrtScene* s, const CgrtRay* rays, uint32_t n, CgrtHit* h
     if (r.readers.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // last one out: the ring is free for generation gen + 1
         r.copied.store(0, std::memory_order_relaxed);
         r.word.store(C::pack(C::FREE, 0, 0, (uint64_t)(gen + 1u)), std::memory_order_release);
+        cb.epoch.fetch_add(1, std::memory_order_seq_cst);
+        if (cb.epoch_sleepers.load(std::memory_order_seq_cst) > 0) futex_wake_all(cb.epoch);
     }
     return 1;
 }

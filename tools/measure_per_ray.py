@@ -21,11 +21,26 @@ cam = pkg.scenes.default_camera(W, H)
 rays = orc.generate_rays(cam, W, H)
 print(f"host: {os.cpu_count()} hardware threads, {CPUS} usable (cgroup quota); scene monkey-rotated.obj ({sd.ntris} triangles), {W}x{H}")
 QUICK = os.environ.get("PER_RAY_QUICK") == "1"  # only the call-rate table with combining on
+
+
+def throttled_ms():
+    """Milliseconds this cgroup has spent throttled by its CPU quota so far (cgroup v2 cpu.stat), or None."""
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1]) / 1e3
+    except OSError:
+        pass
+    return None
+
+
 for combining in ((True,) if QUICK else (False, True)):
     pkg.set_call_combining(combining)
     for T in (1, 8, 64, 256):
         n = min(len(rays), 4000 * T if combining else 1500 * T)
+        thr0, t0 = throttled_ms(), time.time()
         bad, tim = pkg.host_threads_test(sd, rays[:n], nthreads=T)
+        thr1, t1 = throttled_ms(), time.time()
         print(f"call combining {'on ' if combining else 'off'} {T:4d} threads: {tim['calls_per_second']:10.0f} per-ray calls/s "
               f"({tim['us_per_call_per_thread']:7.1f} us per call per thread; one thread alone {tim['us_per_call_one_thread']:.1f} us), disagreements {bad}"
               + (f"; {tim['combined_rays'] / max(1, tim['combined_generations']):.1f} rays per launch on average (largest {tim['largest_generation']}), "
