@@ -44,7 +44,8 @@ for combining in ((True,) if QUICK else (False, True)):
         print(f"call combining {'on ' if combining else 'off'} {T:4d} threads: {tim['calls_per_second']:10.0f} per-ray calls/s "
               f"({tim['us_per_call_per_thread']:7.1f} us per call per thread; one thread alone {tim['us_per_call_one_thread']:.1f} us), disagreements {bad}"
               + (f"; {tim['combined_rays'] / max(1, tim['combined_generations']):.1f} rays per launch on average (largest {tim['largest_generation']}), "
-                 f"{tim['leader_gpu_us_per_generation']:.1f} us launch + kernel + wait per launch, {tim['leader_launch_us_per_generation']:.1f} of them up to the launch call's return" if combining else ""), flush=True)
+                 f"{tim['leader_gpu_us_per_generation']:.1f} us launch + kernel + wait per launch, {tim['leader_launch_us_per_generation']:.1f} of them up to the launch call's return" if combining else "")
+              + (f"; cgroup throttled {thr1 - thr0:.0f} CPU-ms during the test's {1e3 * (t1 - t0):.0f} ms" if thr0 is not None else ""), flush=True)
 pkg.set_call_combining(True)
 if QUICK:
     sys.exit(0)
