@@ -41,6 +41,7 @@ thread_local std::string g_err;
 std::mutex g_options_mutex;
 BuildOptions g_build_options;
 std::atomic<int> g_call_combining{1};  // cgrt_set_call_combining
+std::atomic<int> g_render_predict{1};  // cgrt_set_render_prediction
 std::atomic<int> g_primary_mode{0};  // 0 = one wave per tile, 1 = persistent waves with lane refill
 
 int fail(int code, const std::string& msg) {
@@ -246,7 +247,7 @@ struct CgrtScene {
     struct WorkSlot {
         void* p = nullptr;
         size_t cap = 0;
-    } work[32];  // slots 0..28 are in use (render_impl)
+    } work[32];  // slots 0..29 are in use (render_impl)
     // pinned host staging of cgrt_render*'s frame (grown on demand, guarded by render_mutex): the device frame comes down with ONE
     // asynchronous copy at PCIe speed; cgrt_render_mapped hands this memory to the caller instead of copying it once more
     void* pin_frame = nullptr;
@@ -257,7 +258,18 @@ struct CgrtScene {
         hipStream_t s = nullptr, copy = nullptr;  // second traversal stream; read-backs that must not wait for queued kernels
         hipEvent_t spawned = nullptr, traced = nullptr, e0 = nullptr, e1 = nullptr, primary_done = nullptr;
         uint32_t* pin_counts = nullptr;  // 64 pinned bytes for counter read-backs
+        SpawnDev spawn_host{};           // what the workspace's SpawnDev (fused level-0 spawn of predicted frames) holds
+        bool spawn_valid = false;
     } raux;
+    // What the previous cgrt_render* frame of this shape found, per level (entries of the level's compact list): the next frame's
+    // launches are sized from it and issued WITHOUT waiting for the device to say how many primary rays hit (render_impl).
+    struct RenderPred {
+        bool valid = false;
+        int W = 0, H = 0, rank = 0, nranks = 0, max_level = 0;
+        unsigned L = 0;
+        std::vector<uint32_t> counts;
+        int last_path = 0;  // how the last frame was drawn: 0 exact, 1 as predicted, 2 predicted, found too small, drawn again exactly
+    } rpred;
     uint64_t device_bytes = 0;
     ~CgrtScene() {
         if (device < 0) return;
@@ -1136,6 +1148,11 @@ int cgrt_debug_combiner_stats(const CgrtScene* s, uint64_t* out4) {  // (five wo
     out4[4] = s->comb.ns_launch.load();
     return CGRT_OK;
 }
+int cgrt_debug_render_path(const CgrtScene* s) { return s ? s->rpred.last_path : -1; }
+int cgrt_set_render_prediction(int enabled) {
+    g_render_predict.store(enabled ? 1 : 0);
+    return CGRT_OK;
+}
 int cgrt_set_call_combining(int enabled) {
     g_call_combining.store(enabled ? 1 : 0);
     return CGRT_OK;
@@ -1398,7 +1415,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     WsBuf rays[3] = {{s, 0}, {s, 1}, {s, 21}}, hits[3] = {{s, 2}, {s, 3}, {s, 22}}, normals[3] = {{s, 4}, {s, 5}, {s, 23}},
           pix[3] = {{s, 6}, {s, 7}, {s, 24}}, ipix{s, 8}, srays[2] = {{s, 9}, {s, 25}}, shits[2] = {{s, 10}, {s, 26}}, sdist[2] = {{s, 11}, {s, 27}},
           sslot[2] = {{s, 12}, {s, 28}}, dlights{s, 13}, levels{s, 14}, drgb{s, 15}, dctr{s, 16}, dslights{s, 17}, dunits{s, 18}, dlit{s, 19},
-          dwork{s, 20};
+          dwork{s, 20}, dspawn{s, 29};
     unsigned long long *cw_primary = nullptr, *cw_shadow = nullptr, *cw_mirror = nullptr;
     if (counted) {
         HIP_TRY(dwork.alloc(3 * 8 * sizeof(unsigned long long)));
@@ -1407,6 +1424,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         cw_shadow = cw_primary + 8;
         cw_mirror = cw_primary + 16;
     }
+    HIP_TRY(dspawn.alloc(sizeof(SpawnDev)));
     HIP_TRY(ipix.alloc(n * 4));  // pixels of level 0, kept to the end
     for (int k = 0; k < 3; k++) {
         HIP_TRY(rays[k].alloc(n * 28));
@@ -1461,155 +1479,309 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         HIP_TRY(hipEventCreate(&aux.e1));
         HIP_TRY(hipHostMalloc((void**)&aux.pin_counts, 64, hipHostMallocDefault));
     }
-    HIP_TRY(hipEventRecord(aux.e0, nullptr));
-    int nlev = 0;
-    bool finished = false;  // the frame's last kernels and its closing event have been issued inside the level loop
-    std::vector<unsigned long long> level_count;  // entries per evaluated level
-    HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
-    if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
-        // level 0 = the primary rays that hit something, straight out of the fused primary kernel (pixels that miss are
-        // black, main.cpp:293, and spawn nothing)
-        uint32_t* const primary_hits = dctr.as<uint32_t>() + 4 * (size_t)max_level + 3;
-        HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(),
-                                             ipix.as<int>(), primary_hits, nullptr, cw_primary, drgb.as<float>()));  // (also clears this rank's pixels)
-        st.primary_rays = owned_pixels(F);
-        const float* const mats = static_cast<const float*>(s->d_materials);
-        // Level 0's spawn does not wait for the host to learn how many primary rays hit: it is launched over every item of the
-        // rank's frame and stops at the count it reads on the device, while the host fetches that count on a stream of its own
-        // (behind the primary kernel only) to size the traversal launches that follow -- the host round trip (~25 us of an idle
-        // GPU per frame, profiles/r3_config3_timeline.txt) now overlaps the spawn kernel.
-        HIP_TRY(hipEventRecord(aux.primary_done, nullptr));
-        HIP_TRY(launch_spawn(rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), ipix.as<int>(), n, mats, dlights.as<float>(), L,
-                             1 < max_level, srays[0].as<float>(), sdist[0].as<float>(), sslot[0].as<int>(), levels.as<float>(), rays[1].as<float>(),
-                             pix[1].as<int>(), dctr.as<uint32_t>(), nullptr, primary_hits));
-        // (Issuing level 0's shadow list here too, over its capacity n * L, was measured: Cornell 0.182 -> 0.179 ms, but the dragon
-        // frame 0.46 -> 0.50 ms -- a grid of 32 K workgroups for 318 K rays costs more than the round trip it saves.  It is sized
-        // exactly after the read-back, and issued FIRST: it used to start 64 us after the spawn kernel ended, behind the second
-        // stream's five launches, profiles/r3_config3_timeline.txt.)
-        HIP_TRY(hipEventRecord(aux.spawned, nullptr));
-        HIP_TRY(hipStreamWaitEvent(aux.copy, aux.primary_done, 0));
-        HIP_TRY(hipMemcpyAsync(aux.pin_counts, primary_hits, sizeof(uint32_t), hipMemcpyDeviceToHost, aux.copy));
-        HIP_TRY(hipStreamSynchronize(aux.copy));
-        unsigned long long cnt = aux.pin_counts[0];
-        int level = 0;
-        while (level < max_level && cnt > 0) {
-            const int a = level % 3, b = (level + 1) % 3, q = level & 1;  // this level's buffer set, the next level's, this level's shadow set
-            const int spawn = level + 1 < max_level;
-            const int* cur_pix = level == 0 ? ipix.as<int>() : pix[a].as<int>();
-            uint32_t* ctr = dctr.as<uint32_t>() + 4 * (size_t)level;
-            float* lvl = levels.as<float>() + (size_t)level * n * 8;
-            if (level > 0)  // (level 0's spawn is already in flight, see above)
-                HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), cur_pix, cnt, mats, dlights.as<float>(), L,
-                                     spawn, srays[q].as<float>(), sdist[q].as<float>(), sslot[q].as<int>(), lvl, rays[b].as<float>(), pix[b].as<int>(),
-                                     ctr, nullptr));
-            // Level 0's mirror batch runs on the second stream, beside level 0's shadow batch (two batches of a few hundred
-            // thousand rays each; its grid covers the list's capacity -- one mirror ray per entry -- and the kernel stops at the
-            // appended count).  Without spherical lights the whole of level 1 follows it there -- spawn, shadow list, shading,
-            // level 2's mirror batch: none of it needs level 0's shading, all of it is sized by counts on the device -- so that
-            // level 1's tail overlaps level 0's.  Deeper levels are small and often empty: they run one after the other,
-            // exactly sized after each level's read-back, or not at all.
-            // the level's shadow list first: the long pole of the default stream must not wait behind the second stream's launches
-            if (L)
-                HIP_TRY(launch_trace_shadow(s->dev, srays[q].as<float>(), sdist[q].as<float>(), cnt * L, shits[q].as<CgrtHitDev>(), nullptr, ctr + 0,
-                                            cw_shadow));
-            const bool overlap = spawn && level == 0;
-            const bool pipelined = overlap && SL == 0;
-            const int spawn1 = 2 < max_level;
-            uint32_t* const ctr1 = dctr.as<uint32_t>() + 4;
-            if (overlap) {  // (level 0: aux.spawned was recorded right behind the spawn kernel)
-                HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
-                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cnt, hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, aux.s,
-                                           ctr + 1));
-                if (pipelined) {
-                    const int a1 = b, b1 = 2, q1 = 1;
-                    float* lvl1 = levels.as<float>() + (size_t)n * 8;
-                    HIP_TRY(launch_spawn(rays[a1].as<float>(), hits[a1].as<CgrtHitDev>(), normals[a1].as<float>(), pix[a1].as<int>(), cnt, mats,
-                                         dlights.as<float>(), L, spawn1, srays[q1].as<float>(), sdist[q1].as<float>(), sslot[q1].as<int>(), lvl1,
-                                         rays[b1].as<float>(), pix[b1].as<int>(), ctr1, aux.s, ctr + 1));
-                    if (L)
-                        HIP_TRY(launch_trace_shadow(s->dev, srays[q1].as<float>(), sdist[q1].as<float>(), cnt * L, shits[q1].as<CgrtHitDev>(), aux.s,
-                                                    ctr1 + 0, cw_shadow));
-                    HIP_TRY(launch_shade(rays[a1].as<float>(), hits[a1].as<CgrtHitDev>(), normals[a1].as<float>(), shits[q1].as<CgrtHitDev>(),
-                                         sdist[q1].as<float>(), sslot[q1].as<int>(), cnt, mats, dlights.as<float>(), L, dslights.as<float>(), SL,
-                                         dlit.as<uint32_t>(), Q.samples, lvl1, aux.s, ctr + 1));
-                    if (spawn1)
-                        HIP_TRY(launch_trace_batch(s->dev, rays[b1].as<float>(), cnt, hits[b1].as<CgrtHitDev>(), normals[b1].as<float>(), cw_mirror,
-                                                   aux.s, ctr1 + 1));
-                }
-                HIP_TRY(hipEventRecord(aux.traced, aux.s));
-            }
-            if (SL) {
-                Q.level = (uint32_t)level;
-                HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));
-                HIP_TRY(launch_soft_shadow(s->dev, Q, rays[a].as<float>(), hits[a].as<CgrtHitDev>(), cur_pix, cnt, dlit.as<uint32_t>(),
-                                           soft->closest_hit == 0, nullptr));
-            }
-            HIP_TRY(launch_shade(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), shits[q].as<CgrtHitDev>(), sdist[q].as<float>(),
-                                 sslot[q].as<int>(), cnt, mats, dlights.as<float>(), L, dslights.as<float>(), SL, dlit.as<uint32_t>(), Q.samples, lvl,
-                                 nullptr));
-            if (overlap) HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));  // the next level (and the end of the frame) need the second stream's results
-            nlev = level + 1;
-            level_count.push_back(cnt);
-            if (pipelined && !spawn1) {
-                // Depth 2 (the reference's own depth, main.cpp:267): both levels are in flight or done and nothing further depends
-                // on their counts -- the frame is finished without a host round trip (an entry of level 0 without a mirror ray
-                // carries child = -1, so the scatter kernel can fold with level 1 whether or not level 1 has entries); the
-                // counts are read after the frame's closing event.
-                HIP_TRY(launch_write_rgb(levels.as<float>(), levels.as<float>() + (size_t)n * 8, cnt, ipix.as<int>(), drgb.as<float>(), nullptr));
-                finished = true;
-                HIP_TRY(hipEventRecord(aux.e1, nullptr));
-                uint32_t h2[8];
-                HIP_TRY(hipMemcpy(h2, ctr, sizeof(h2), hipMemcpyDeviceToHost));  // levels 0 and 1, adjacent
-                st.shadow_rays += (uint64_t)h2[0] + h2[4];
-                st.reflection_rays += (uint64_t)h2[1] + h2[5];
-                if (h2[1] > 0) {
-                    nlev = 2;
-                    level_count.push_back(h2[1]);
-                }
-                break;
-            }
-            uint32_t h[8];
-            HIP_TRY(hipMemcpy(h, ctr, pipelined ? sizeof(h) : sizeof(h) / 2, hipMemcpyDeviceToHost));  // also the level's sync point (pipelined: levels 0 and 1, adjacent)
-            st.shadow_rays += h[0];
-            st.reflection_rays += h[1];
-            st.soft_shadow_rays += (uint64_t)h[2] * SL * Q.samples;
-            if (!spawn || h[1] == 0) break;
-            if (pipelined) {  // level 1 has been evaluated on the second stream, and level 2's rays traversed
-                const uint32_t* h1 = h + 4;
-                nlev = 2;
-                level_count.push_back(h[1]);
-                st.shadow_rays += h1[0];
-                st.reflection_rays += h1[1];
-                if (!spawn1 || h1[1] == 0) break;
-                cnt = h1[1];
-                level = 2;
-                continue;
-            }
-            if (!overlap)
-                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), h[1], hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, nullptr));
-            cnt = h[1];
-            level += 1;
+    const float* const mats = static_cast<const float*>(s->d_materials);
+    uint32_t* const primary_hits = dctr.as<uint32_t>() + 4 * (size_t)max_level + 3;
+    auto ctr_of = [&](int level) { return dctr.as<uint32_t>() + 4 * (size_t)level; };
+    auto lvl_of = [&](int level) { return levels.as<float>() + (size_t)level * n * 8; };
+    // ---- The frame as the previous frame of this shape predicts it ----
+    // An interactive renderer draws the same scene again and again (main.cpp:776-797 re-renders on every camera change), and what
+    // stands between the kernels of one frame is the HOST learning list lengths: a read-back and a round trip (~25-40 us of an
+    // idle GPU, profiles/r3_config3_timeline.txt) after the primary kernel, and another one per level beyond the second.  Here
+    // every launch of the frame is issued at once: grids cover 1.125 x the previous frame's entries of that level + 1024, the
+    // kernels stop at the counts they read on the device, and levels the previous frame did not reach are not issued.  The
+    // counters come back once, behind the frame; if any list outgrew its grid, or a level that was not issued turns out to have
+    // entries, the frame is drawn again the exact way below (first frames, resized frames and frames with spherical lights or
+    // work counters always are).  Same kernels on the same lists: the frame is bit-identical either way (tests/test_render_gpu.py).
+    bool frame_done = false;
+    CgrtScene::RenderPred& P = s->rpred;
+    const bool predictable = g_render_predict.load() && P.valid && P.W == W && P.H == H && P.rank == rank && P.nranks == nranks &&
+                             P.max_level == max_level && P.L == L && !P.counts.empty() && SL == 0 && !counted && max_level >= 1;
+    auto predicted = [&]() -> int {
+        const int np = (int)P.counts.size();  // levels the previous frame evaluated (P.counts[l] > 0 entries each)
+        // {level 0's entries, level 1's entries}: one 64-bit word, filled by the primary kernel's fused spawn with one atomic
+        uint32_t* const pair = dctr.as<uint32_t>() + 4 * (size_t)max_level + 2;
+        auto count_of = [&](int level) { return level <= 1 ? pair + level : ctr_of(level - 1) + 1; };  // device word: entries of the level
+        auto cap_of = [&](int level) { return std::min<unsigned long long>(n, (unsigned long long)P.counts[level] + P.counts[level] / 8 + 1024); };
+        HIP_TRY(hipEventRecord(aux.e0, nullptr));
+        HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
+        // (level 0's spawn is done by the primary kernel itself, from the registers of the lanes that hit: spawn_rays.h)
+        SpawnDev SP{};
+        SP.materials = mats;
+        SP.lights = dlights.as<float>();
+        SP.nlights = L;
+        SP.spawn = 1 < max_level;
+        SP.srays = srays[0].as<float>();
+        SP.sdist = sdist[0].as<float>();
+        SP.sslot = sslot[0].as<int>();
+        SP.lvl = reinterpret_cast<float4*>(lvl_of(0));
+        SP.next_rays = rays[1].as<float>();
+        SP.next_pixels = pix[1].as<int>();
+        if (!aux.spawn_valid || std::memcmp(&SP, &aux.spawn_host, sizeof(SP)) != 0) {  // (the workspace keeps its addresses from frame to frame)
+            HIP_TRY(hipMemcpy(dspawn.p, &SP, sizeof(SP), hipMemcpyHostToDevice));
+            aux.spawn_host = SP;
+            aux.spawn_valid = true;
         }
+        HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), ipix.as<int>(),
+                                             pair, nullptr, nullptr, drgb.as<float>(), static_cast<const SpawnDev*>(dspawn.p)));
+        const unsigned long long cap0 = cap_of(0);
+        HIP_TRY(hipEventRecord(aux.spawned, nullptr));
+        if (L)
+            HIP_TRY(launch_trace_shadow(s->dev, srays[0].as<float>(), sdist[0].as<float>(), cap0 * L, shits[0].as<CgrtHitDev>(), nullptr, pair,
+                                        nullptr, (unsigned long long)P.counts[0] * L, L));  // (hits x lights rays)
+        if (np >= 2) {  // level 0's mirror list and the whole of level 1 on the second stream, beside level 0's shadow list
+            const unsigned long long cap1 = cap_of(1);
+            HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
+            HIP_TRY(launch_trace_batch(s->dev, rays[1].as<float>(), cap1, hits[1].as<CgrtHitDev>(), normals[1].as<float>(), nullptr, aux.s, pair + 1,
+                                       P.counts[1]));
+            HIP_TRY(launch_spawn(rays[1].as<float>(), hits[1].as<CgrtHitDev>(), normals[1].as<float>(), pix[1].as<int>(), cap1, mats, dlights.as<float>(), L,
+                                 2 < max_level, srays[1].as<float>(), sdist[1].as<float>(), sslot[1].as<int>(), lvl_of(1), rays[2].as<float>(),
+                                 pix[2].as<int>(), ctr_of(1), aux.s, pair + 1));
+            if (L)
+                HIP_TRY(launch_trace_shadow(s->dev, srays[1].as<float>(), sdist[1].as<float>(), cap1 * L, shits[1].as<CgrtHitDev>(), aux.s, ctr_of(1) + 0,
+                                            nullptr, (unsigned long long)P.counts[1] * L));
+            HIP_TRY(launch_shade(rays[1].as<float>(), hits[1].as<CgrtHitDev>(), normals[1].as<float>(), shits[1].as<CgrtHitDev>(), sdist[1].as<float>(),
+                                 sslot[1].as<int>(), cap1, mats, dlights.as<float>(), L, dslights.as<float>(), 0, dlit.as<uint32_t>(), Q.samples, lvl_of(1),
+                                 aux.s, pair + 1));
+            if (np >= 3)
+                HIP_TRY(launch_trace_batch(s->dev, rays[2].as<float>(), cap_of(2), hits[2].as<CgrtHitDev>(), normals[2].as<float>(), nullptr, aux.s,
+                                           ctr_of(1) + 1, P.counts[2]));
+            HIP_TRY(hipEventRecord(aux.traced, aux.s));
+        }
+        HIP_TRY(launch_shade(rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), shits[0].as<CgrtHitDev>(), sdist[0].as<float>(),
+                             sslot[0].as<int>(), cap0, mats, dlights.as<float>(), L, dslights.as<float>(), 0, dlit.as<uint32_t>(), Q.samples, lvl_of(0), nullptr,
+                             pair));
+        // Two levels (the reference's depth, and most frames at any depth): the frame's last kernels are on the second stream, so
+        // the scatter into the frame goes there too, behind level 0's shading -- which finished long before -- instead of the
+        // default stream waiting for the second one (a cross-stream wait in front of the last kernel cost ~10 us of idle GPU).
+        const bool tail_on_aux = np == 2;
+        if (tail_on_aux) {
+            HIP_TRY(hipEventRecord(aux.primary_done, nullptr));  // (reused: level 0 is shaded)
+            HIP_TRY(hipStreamWaitEvent(aux.s, aux.primary_done, 0));
+        } else if (np >= 2) {
+            HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));
+        }
+        hipStream_t const tail = tail_on_aux ? aux.s : nullptr;
+        for (int level = 2; level < np; level++) {  // deeper levels: small, one after the other (buffer sets as in the exact path)
+            const int a = level % 3, b = (level + 1) % 3, q = level & 1;
+            const unsigned long long cap = cap_of(level);
+            HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), pix[a].as<int>(), cap, mats, dlights.as<float>(), L,
+                                 level + 1 < max_level, srays[q].as<float>(), sdist[q].as<float>(), sslot[q].as<int>(), lvl_of(level), rays[b].as<float>(),
+                                 pix[b].as<int>(), ctr_of(level), nullptr, count_of(level)));
+            if (L)
+                HIP_TRY(launch_trace_shadow(s->dev, srays[q].as<float>(), sdist[q].as<float>(), cap * L, shits[q].as<CgrtHitDev>(), nullptr,
+                                            ctr_of(level) + 0, nullptr, (unsigned long long)P.counts[level] * L));
+            HIP_TRY(launch_shade(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), shits[q].as<CgrtHitDev>(), sdist[q].as<float>(),
+                                 sslot[q].as<int>(), cap, mats, dlights.as<float>(), L, dslights.as<float>(), 0, dlit.as<uint32_t>(), Q.samples, lvl_of(level),
+                                 nullptr, count_of(level)));
+            if (level + 1 < np)
+                HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cap_of(level + 1), hits[b].as<CgrtHitDev>(), normals[b].as<float>(), nullptr, nullptr,
+                                           ctr_of(level) + 1, P.counts[level + 1]));
+        }
+        for (int level = np - 2; level >= 1; level--) HIP_TRY(launch_fold(lvl_of(level), lvl_of(level + 1), cap_of(level), nullptr, count_of(level)));
+        HIP_TRY(launch_write_rgb(lvl_of(0), np >= 2 ? lvl_of(1) : nullptr, cap0, ipix.as<int>(), drgb.as<float>(), tail, pair));
+        HIP_TRY(hipEventRecord(aux.e1, tail));
+        HIP_TRY(hipEventSynchronize(aux.e1));
+        std::vector<uint32_t> hc(nctr);
+        HIP_TRY(hipMemcpy(hc.data(), dctr.p, nctr * sizeof(uint32_t), hipMemcpyDeviceToHost));  // (waits for the frame)
+        // ---- did every list fit its grid, and did the frame end where it was expected to? ----
+        std::vector<uint32_t> actual;  // entries per level, levels with entries only
+        bool fits = true;
+        for (int level = 0; level < max_level; level++) {
+            const uint32_t cnt = level <= 1 ? hc[4 * (size_t)max_level + 2 + level] : hc[4 * (size_t)(level - 1) + 1];
+            if (level < np) {
+                fits = fits && cnt <= cap_of(level);
+            } else {
+                fits = fits && cnt == 0;  // a level that was not issued has entries
+            }
+            if (cnt == 0 || !fits) break;
+            actual.push_back(cnt);
+        }
+        if (!fits) {
+            P.valid = false;
+            return CGRT_OK;  // (frame_done stays false: the exact path draws the frame)
+        }
+        st.primary_rays = owned_pixels(F);
+        st.shadow_rays = (uint64_t)actual[0] * L;  // (level 0's counter block is not used by the fused spawn)
+        st.reflection_rays = hc[4 * (size_t)max_level + 3];
+        for (size_t level = 1; level < actual.size(); level++) {
+            st.shadow_rays += hc[4 * level + 0];
+            st.reflection_rays += hc[4 * level + 1];
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, aux.e0, aux.e1));
+        st.device_ms = ms;
+        st.levels = (int)actual.size();
+        P.counts = actual;
+        P.valid = !actual.empty();
+        P.last_path = 1;
+        frame_done = true;
+        return CGRT_OK;
+    };
+    if (predictable) {
+        const int prc = predicted();
+        if (prc != CGRT_OK) return prc;
     }
-    if (finished) {
-    } else if (max_level < 1) {  // trace() returns black without tracing (main.cpp:267): no primary kernel ran, clear here
-        HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
-    } else if (nlev == 0) {  // nothing was hit: the primary kernel has left this rank's pixels black
-    } else {
-        // color = directColor + reflectedColor * ks (main.cpp:262), deepest level first; the last fold (level 0 with level 1) is
-        // done by the kernel that scatters level 0 over the frame
-        for (int level = nlev - 2; level >= 1; level--)
-            HIP_TRY(launch_fold(levels.as<float>() + (size_t)level * n * 8, levels.as<float>() + (size_t)(level + 1) * n * 8, level_count[level],
-                                nullptr));
-        HIP_TRY(launch_write_rgb(levels.as<float>(), nlev >= 2 ? levels.as<float>() + (size_t)n * 8 : nullptr, level_count[0], ipix.as<int>(),
-                                 drgb.as<float>(), nullptr));
+    auto exact = [&]() -> int {
+        HIP_TRY(hipEventRecord(aux.e0, nullptr));
+        int nlev = 0;
+        bool finished = false;  // the frame's last kernels and its closing event have been issued inside the level loop
+        std::vector<unsigned long long> level_count;  // entries per evaluated level
+        HIP_TRY(hipMemsetAsync(dctr.p, 0, nctr * sizeof(uint32_t), nullptr));
+        if (max_level >= 1) {  // trace(level 0): main.cpp:267 returns black without tracing when level >= maxLevel
+            // level 0 = the primary rays that hit something, straight out of the fused primary kernel (pixels that miss are
+            // black, main.cpp:293, and spawn nothing)
+            HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(),
+                                                 ipix.as<int>(), primary_hits, nullptr, cw_primary, drgb.as<float>()));  // (also clears this rank's pixels)
+            st.primary_rays = owned_pixels(F);
+            // Level 0's spawn does not wait for the host to learn how many primary rays hit: it is launched over every item of the
+            // rank's frame and stops at the count it reads on the device, while the host fetches that count on a stream of its own
+            // (behind the primary kernel only) to size the traversal launches that follow -- the host round trip (~25 us of an idle
+            // GPU per frame, profiles/r3_config3_timeline.txt) now overlaps the spawn kernel.
+            HIP_TRY(hipEventRecord(aux.primary_done, nullptr));
+            HIP_TRY(launch_spawn(rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), ipix.as<int>(), n, mats, dlights.as<float>(), L,
+                                 1 < max_level, srays[0].as<float>(), sdist[0].as<float>(), sslot[0].as<int>(), levels.as<float>(), rays[1].as<float>(),
+                                 pix[1].as<int>(), dctr.as<uint32_t>(), nullptr, primary_hits));
+            // (Issuing level 0's shadow list here too, over its capacity n * L, was measured: Cornell 0.182 -> 0.179 ms, but the dragon
+            // frame 0.46 -> 0.50 ms -- a grid of 32 K workgroups for 318 K rays costs more than the round trip it saves.  It is sized
+            // exactly after the read-back, and issued FIRST: it used to start 64 us after the spawn kernel ended, behind the second
+            // stream's five launches, profiles/r3_config3_timeline.txt.)
+            HIP_TRY(hipEventRecord(aux.spawned, nullptr));
+            HIP_TRY(hipStreamWaitEvent(aux.copy, aux.primary_done, 0));
+            HIP_TRY(hipMemcpyAsync(aux.pin_counts, primary_hits, sizeof(uint32_t), hipMemcpyDeviceToHost, aux.copy));
+            HIP_TRY(hipStreamSynchronize(aux.copy));
+            unsigned long long cnt = aux.pin_counts[0];
+            int level = 0;
+            while (level < max_level && cnt > 0) {
+                const int a = level % 3, b = (level + 1) % 3, q = level & 1;  // this level's buffer set, the next level's, this level's shadow set
+                const int spawn = level + 1 < max_level;
+                const int* cur_pix = level == 0 ? ipix.as<int>() : pix[a].as<int>();
+                uint32_t* ctr = dctr.as<uint32_t>() + 4 * (size_t)level;
+                float* lvl = levels.as<float>() + (size_t)level * n * 8;
+                if (level > 0)  // (level 0's spawn is already in flight, see above)
+                    HIP_TRY(launch_spawn(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), cur_pix, cnt, mats, dlights.as<float>(), L,
+                                         spawn, srays[q].as<float>(), sdist[q].as<float>(), sslot[q].as<int>(), lvl, rays[b].as<float>(), pix[b].as<int>(),
+                                         ctr, nullptr));
+                // Level 0's mirror batch runs on the second stream, beside level 0's shadow batch (two batches of a few hundred
+                // thousand rays each; its grid covers the list's capacity -- one mirror ray per entry -- and the kernel stops at the
+                // appended count).  Without spherical lights the whole of level 1 follows it there -- spawn, shadow list, shading,
+                // level 2's mirror batch: none of it needs level 0's shading, all of it is sized by counts on the device -- so that
+                // level 1's tail overlaps level 0's.  Deeper levels are small and often empty: they run one after the other,
+                // exactly sized after each level's read-back, or not at all.
+                // the level's shadow list first: the long pole of the default stream must not wait behind the second stream's launches
+                if (L)
+                    HIP_TRY(launch_trace_shadow(s->dev, srays[q].as<float>(), sdist[q].as<float>(), cnt * L, shits[q].as<CgrtHitDev>(), nullptr, ctr + 0,
+                                                cw_shadow));
+                const bool overlap = spawn && level == 0;
+                const bool pipelined = overlap && SL == 0;
+                const int spawn1 = 2 < max_level;
+                uint32_t* const ctr1 = dctr.as<uint32_t>() + 4;
+                if (overlap) {  // (level 0: aux.spawned was recorded right behind the spawn kernel)
+                    HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
+                    HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), cnt, hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, aux.s,
+                                               ctr + 1));
+                    if (pipelined) {
+                        const int a1 = b, b1 = 2, q1 = 1;
+                        float* lvl1 = levels.as<float>() + (size_t)n * 8;
+                        HIP_TRY(launch_spawn(rays[a1].as<float>(), hits[a1].as<CgrtHitDev>(), normals[a1].as<float>(), pix[a1].as<int>(), cnt, mats,
+                                             dlights.as<float>(), L, spawn1, srays[q1].as<float>(), sdist[q1].as<float>(), sslot[q1].as<int>(), lvl1,
+                                             rays[b1].as<float>(), pix[b1].as<int>(), ctr1, aux.s, ctr + 1));
+                        if (L)
+                            HIP_TRY(launch_trace_shadow(s->dev, srays[q1].as<float>(), sdist[q1].as<float>(), cnt * L, shits[q1].as<CgrtHitDev>(), aux.s,
+                                                        ctr1 + 0, cw_shadow));
+                        HIP_TRY(launch_shade(rays[a1].as<float>(), hits[a1].as<CgrtHitDev>(), normals[a1].as<float>(), shits[q1].as<CgrtHitDev>(),
+                                             sdist[q1].as<float>(), sslot[q1].as<int>(), cnt, mats, dlights.as<float>(), L, dslights.as<float>(), SL,
+                                             dlit.as<uint32_t>(), Q.samples, lvl1, aux.s, ctr + 1));
+                        if (spawn1)
+                            HIP_TRY(launch_trace_batch(s->dev, rays[b1].as<float>(), cnt, hits[b1].as<CgrtHitDev>(), normals[b1].as<float>(), cw_mirror,
+                                                       aux.s, ctr1 + 1));
+                    }
+                    HIP_TRY(hipEventRecord(aux.traced, aux.s));
+                }
+                if (SL) {
+                    Q.level = (uint32_t)level;
+                    HIP_TRY(hipMemsetAsync(dlit.p, 0, cnt * SL * 4, nullptr));
+                    HIP_TRY(launch_soft_shadow(s->dev, Q, rays[a].as<float>(), hits[a].as<CgrtHitDev>(), cur_pix, cnt, dlit.as<uint32_t>(),
+                                               soft->closest_hit == 0, nullptr));
+                }
+                HIP_TRY(launch_shade(rays[a].as<float>(), hits[a].as<CgrtHitDev>(), normals[a].as<float>(), shits[q].as<CgrtHitDev>(), sdist[q].as<float>(),
+                                     sslot[q].as<int>(), cnt, mats, dlights.as<float>(), L, dslights.as<float>(), SL, dlit.as<uint32_t>(), Q.samples, lvl,
+                                     nullptr));
+                if (overlap) HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));  // the next level (and the end of the frame) need the second stream's results
+                nlev = level + 1;
+                level_count.push_back(cnt);
+                if (pipelined && !spawn1) {
+                    // Depth 2 (the reference's own depth, main.cpp:267): both levels are in flight or done and nothing further depends
+                    // on their counts -- the frame is finished without a host round trip (an entry of level 0 without a mirror ray
+                    // carries child = -1, so the scatter kernel can fold with level 1 whether or not level 1 has entries); the
+                    // counts are read after the frame's closing event.
+                    HIP_TRY(launch_write_rgb(levels.as<float>(), levels.as<float>() + (size_t)n * 8, cnt, ipix.as<int>(), drgb.as<float>(), nullptr));
+                    finished = true;
+                    HIP_TRY(hipEventRecord(aux.e1, nullptr));
+                    uint32_t h2[8];
+                    HIP_TRY(hipMemcpy(h2, ctr, sizeof(h2), hipMemcpyDeviceToHost));  // levels 0 and 1, adjacent
+                    st.shadow_rays += (uint64_t)h2[0] + h2[4];
+                    st.reflection_rays += (uint64_t)h2[1] + h2[5];
+                    if (h2[1] > 0) {
+                        nlev = 2;
+                        level_count.push_back(h2[1]);
+                    }
+                    break;
+                }
+                uint32_t h[8];
+                HIP_TRY(hipMemcpy(h, ctr, pipelined ? sizeof(h) : sizeof(h) / 2, hipMemcpyDeviceToHost));  // also the level's sync point (pipelined: levels 0 and 1, adjacent)
+                st.shadow_rays += h[0];
+                st.reflection_rays += h[1];
+                st.soft_shadow_rays += (uint64_t)h[2] * SL * Q.samples;
+                if (!spawn || h[1] == 0) break;
+                if (pipelined) {  // level 1 has been evaluated on the second stream, and level 2's rays traversed
+                    const uint32_t* h1 = h + 4;
+                    nlev = 2;
+                    level_count.push_back(h[1]);
+                    st.shadow_rays += h1[0];
+                    st.reflection_rays += h1[1];
+                    if (!spawn1 || h1[1] == 0) break;
+                    cnt = h1[1];
+                    level = 2;
+                    continue;
+                }
+                if (!overlap)
+                    HIP_TRY(launch_trace_batch(s->dev, rays[b].as<float>(), h[1], hits[b].as<CgrtHitDev>(), normals[b].as<float>(), cw_mirror, nullptr));
+                cnt = h[1];
+                level += 1;
+            }
+        }
+        if (finished) {
+        } else if (max_level < 1) {  // trace() returns black without tracing (main.cpp:267): no primary kernel ran, clear here
+            HIP_TRY(launch_clear_owned(F, drgb.as<float>(), nullptr));
+        } else if (nlev == 0) {  // nothing was hit: the primary kernel has left this rank's pixels black
+        } else {
+            // color = directColor + reflectedColor * ks (main.cpp:262), deepest level first; the last fold (level 0 with level 1) is
+            // done by the kernel that scatters level 0 over the frame
+            for (int level = nlev - 2; level >= 1; level--)
+                HIP_TRY(launch_fold(levels.as<float>() + (size_t)level * n * 8, levels.as<float>() + (size_t)(level + 1) * n * 8, level_count[level],
+                                    nullptr));
+            HIP_TRY(launch_write_rgb(levels.as<float>(), nlev >= 2 ? levels.as<float>() + (size_t)n * 8 : nullptr, level_count[0], ipix.as<int>(),
+                                     drgb.as<float>(), nullptr));
+        }
+        if (!finished) HIP_TRY(hipEventRecord(aux.e1, nullptr));
+        HIP_TRY(hipEventSynchronize(aux.e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, aux.e0, aux.e1));
+        st.device_ms = ms;
+        st.levels = nlev;
+        // what this frame found sizes the next one
+        P.valid = g_render_predict.load() && SL == 0 && !counted && max_level >= 1 && !level_count.empty();
+        P.W = W, P.H = H, P.rank = rank, P.nranks = nranks, P.max_level = max_level, P.L = L;
+        P.counts.clear();
+        for (unsigned long long c : level_count) P.counts.push_back((uint32_t)c);
+        return CGRT_OK;
+    };
+    if (!frame_done) {
+        P.last_path = predictable ? 2 : 0;
+        st = CgrtRenderStats{};
+        const int erc = exact();
+        if (erc != CGRT_OK) return erc;
     }
-    if (!finished) HIP_TRY(hipEventRecord(aux.e1, nullptr));
-    HIP_TRY(hipEventSynchronize(aux.e1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, aux.e0, aux.e1));
-    st.device_ms = ms;
-    st.levels = nlev;
     {
         const size_t bytes = (size_t)npix * 12;
         if (s->pin_frame_cap < bytes) {

@@ -14,6 +14,7 @@
 
 #include "cgrt_layout.h"
 #include "cgrt_math.h"
+#include "spawn_rays.h"
 #include "trace_kernels.h"
 
 namespace cgrt {
@@ -73,41 +74,17 @@ __global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_spawn(const float* __restr
         // a hit that never wrote hitInfo.material (sphere only) reads an indeterminate Material upstream; default Material here
         ks = mid >= 0 ? ldv(materials + 8 * mid + 3) : f3(0.f, 0.f, 0.f);
     }
-    const float eps = 0.001f;
     __shared__ uint32_t s_tmp[CGRT_SHADE_BLOCK / 64 + 1];
     for (unsigned l = 0; l < nlights; l++) {
         const uint32_t idx = block_append(counters + 0, hit, s_tmp);
         if (in) sslot[i * nlights + l] = hit ? (int)idx : -1;
-        if (!hit) continue;
-        const F3 toLight = sub(ldv(lights + 6 * l), pointOn);
-        const F3 dir = normalize(toLight);
-        const F3 o = add(pointOn, f3(eps * dir.x, eps * dir.y, eps * dir.z));  // ray.origin += epsilon * ray.direction
-        float* s = srays + 7ull * idx;
-        s[0] = o.x;
-        s[1] = o.y;
-        s[2] = o.z;
-        s[3] = dir.x;
-        s[4] = dir.y;
-        s[5] = dir.z;
-        s[6] = 3.402823466e+38f;
-        sdist[idx] = length(toLight);
+        if (hit) spawn_shadow_ray(lights, l, pointOn, idx, srays, sdist);
     }
     // :246 tests ks.z only (comma operator); `spawn` = level + 1 < maxLevel (:267)
     const bool wants_mirror = hit && !(ks.z <= 0.01f) && spawn;
     const uint32_t child = block_append(counters + 1, wants_mirror, s_tmp);
     if (wants_mirror) {
-        const F3 nrm = ldv(normals + 3 * i);
-        const float dn = dot(nrm, d);  // glm::reflect(I, N) = I - N * dot(N, I) * 2
-        const F3 refl = normalize(sub(d, scale(scale(nrm, dn), 2.0f)));
-        const F3 ro = add(pointOn, f3(eps * refl.x, eps * refl.y, eps * refl.z));
-        float* q = next_rays + 7ull * child;
-        q[0] = ro.x;
-        q[1] = ro.y;
-        q[2] = ro.z;
-        q[3] = refl.x;
-        q[4] = refl.y;
-        q[5] = refl.z;
-        q[6] = length(d);  // :254: t = |direction| of the parent ray
+        spawn_mirror_ray(pointOn, d, ldv(normals + 3 * i), child, next_rays);
         next_pixels[child] = pixels[i];
     }
     if (in) lvl[2 * i + 1] = make_float4(ks.x, ks.y, ks.z, __int_as_float(wants_mirror ? (int)child : -1));
@@ -192,8 +169,13 @@ __global__ __launch_bounds__(CGRT_SHADE_BLOCK) void k_shade(const float* __restr
 
 // colour = !hit ? 0 : (ks.z <= 0.01 ? direct : direct + childColour * ks)   (main.cpp:248, :262, :293); the child's
 // record already holds its folded colour (levels are folded deepest first).
-__global__ void k_fold(float4* __restrict__ lvl, const float4* __restrict__ child_lvl, unsigned long long n) {
+__global__ void k_fold(float4* __restrict__ lvl, const float4* __restrict__ child_lvl, unsigned long long n,
+                       const uint32_t* __restrict__ dcount) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dcount) {  // (as k_spawn: the grid covers the list's capacity)
+        const unsigned long long present = *dcount;
+        n = present < n ? present : n;
+    }
     if (i >= n) return;
     const float4 a = lvl[2 * i], b = lvl[2 * i + 1];
     const int child = __float_as_int(b.w);
@@ -204,8 +186,12 @@ __global__ void k_fold(float4* __restrict__ lvl, const float4* __restrict__ chil
 
 // child_lvl (optional): the fold of level 0 with level 1 (k_fold's arithmetic) happens here, one launch less
 __global__ void k_write_rgb(const float4* __restrict__ lvl0, const float4* __restrict__ child_lvl, unsigned long long n,
-                            const int* __restrict__ item_pixels, float* __restrict__ rgb) {
+                            const int* __restrict__ item_pixels, float* __restrict__ rgb, const uint32_t* __restrict__ dcount) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dcount) {
+        const unsigned long long present = *dcount;
+        n = present < n ? present : n;
+    }
     if (i >= n) return;
     const long long pix = item_pixels[i];
     if (pix < 0) return;  // item outside the frame
@@ -242,16 +228,17 @@ hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* 
                            materials, lights, nlights, slights, nslights, lit, samples, reinterpret_cast<float4*>(lvl), dcount);
     return hipGetLastError();
 }
-hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s) {
+hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s, const uint32_t* dcount) {
     if (n)
         hipLaunchKernelGGL(k_fold, dim3(grid_for(n, 256)), dim3(256), 0, s, reinterpret_cast<float4*>(lvl),
-                           reinterpret_cast<const float4*>(child_lvl), n);
+                           reinterpret_cast<const float4*>(child_lvl), n, dcount);
     return hipGetLastError();
 }
-hipError_t launch_write_rgb(const float* lvl0, const float* child_lvl, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s) {
+hipError_t launch_write_rgb(const float* lvl0, const float* child_lvl, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s,
+                            const uint32_t* dcount) {
     if (n)
         hipLaunchKernelGGL(k_write_rgb, dim3(grid_for(n, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(lvl0),
-                           reinterpret_cast<const float4*>(child_lvl), n, item_pixels, rgb);
+                           reinterpret_cast<const float4*>(child_lvl), n, item_pixels, rgb, dcount);
     return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "cgrt_layout.h"
+#include "spawn_rays.h"
 
 namespace cgrt {
 
@@ -42,12 +43,14 @@ hipError_t launch_trace_primary_stamped(const SceneDev& S, const CameraDev& C, c
                                         unsigned long long* stamps, hipStream_t stream);
 // dcount (optional): device word with the number of rays actually present (<= n, the capacity the grid is sized for)
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
-                              unsigned long long* counters, hipStream_t stream, const uint32_t* dcount = nullptr);
+                              unsigned long long* counters, hipStream_t stream, const uint32_t* dcount = nullptr,
+                              unsigned long long expected = 0);  // expected (with dcount): the host's estimate of *dcount picks the kernel shape
 // every triangle, no tree (ray_tracing.cpp:202-213); mesh < 0: all meshes + spheres
 hipError_t launch_brute_batch(const SceneDev& S, const float* rays, unsigned long long n, int mesh, CgrtHitDev* hits, float* normals, hipStream_t s);
 // pointInShadow's rays (main.cpp:104-135): hits[i] decides `hit && !(t + 0.001f >= dist[i])` like the reference's closest hit does
 hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
-                               const uint32_t* dcount = nullptr, unsigned long long* counters = nullptr);
+                               const uint32_t* dcount = nullptr, unsigned long long* counters = nullptr, unsigned long long expected = 0,
+                               unsigned dmul = 1);  // dmul: the list holds *dcount x dmul rays
 // *flag = value (system scope) once everything queued on the stream before it has finished
 hipError_t launch_signal(uint32_t* flag, uint32_t value, hipStream_t stream);
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);
@@ -58,7 +61,7 @@ hipError_t launch_soft_shadow(const SceneDev& S, const SoftDev& Q, const float* 
 // primary frame for the shading wavefront: only the hits, appended to a compact list; count = one zeroed device word
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
                                         int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters = nullptr,
-                                        float* rgb = nullptr);  // rgb (optional): the rank's pixels are cleared by the same kernel
+                                        float* rgb = nullptr, const SpawnDev* spawn = nullptr);  // spawn (device memory): level 0's k_spawn fused in (spawn_rays.h)  // rgb (optional): the rank's pixels are cleared by the same kernel
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream);
 // shading wavefront (shade_kernels.hip); every level is a compact list of live paths
 // counters: 3 device words {shadow rays appended, mirror rays appended, hits}, zeroed by the caller
@@ -72,9 +75,11 @@ hipError_t launch_shade(const float* rays, const CgrtHitDev* hits, const float* 
                         const float* slights, unsigned nslights, const uint32_t* lit, unsigned samples, float* lvl, hipStream_t s,
                         const uint32_t* dcount = nullptr);  // dcount (optional): device word with the list's length (<= n, the capacity the grid covers)
 // colour of level `lvl` entries += colour of their child (level lvl + 1) * ks  (main.cpp:262)
-hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s);
+// dcount (optional, also launch_write_rgb): the list's length on the device; n is then its capacity
+hipError_t launch_fold(float* lvl, const float* child_lvl, unsigned long long n, hipStream_t s, const uint32_t* dcount = nullptr);
 // child_lvl (optional): level 0 is folded with level 1 on the fly (colour + childColour * ks, main.cpp:262) instead of by launch_fold
-hipError_t launch_write_rgb(const float* lvl0, const float* child_lvl, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s);
+hipError_t launch_write_rgb(const float* lvl0, const float* child_lvl, unsigned long long n, const int* item_pixels, float* rgb, hipStream_t s,
+                            const uint32_t* dcount = nullptr);
 hipError_t launch_gather_calib(const void* table, unsigned long long nrecords, unsigned long long mult, unsigned long long add, float* sink,
                                hipStream_t s);
 hipError_t launch_fastdiv_check(const float* a, const float* d, unsigned long long n, unsigned long long* mismatches, float* first_bad,

@@ -71,7 +71,7 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
 template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDev F, float* __restrict__ rays, CgrtHitDev* __restrict__ hits,
                                                 float* __restrict__ normals, int* __restrict__ pixels, uint32_t* __restrict__ count,
-                                                unsigned long long* counters, float* __restrict__ rgb) {
+                                                unsigned long long* counters, float* __restrict__ rgb, const SpawnDev* __restrict__ spawn_dev) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     const int lane = threadIdx.x & 63;
     int x = 0, y = 0;
@@ -98,23 +98,47 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
     // one atomic per workgroup (same-address atomics serialise at the L2); the workgroup's LDS is only released when its
     // last wave ends anyway, so waiting for it here costs no occupancy
     const bool keep = active && writer && h.hit != 0;
-    const unsigned long long m = __ballot(keep);
+    // Fused level-0 spawn (a predicted frame, capi.cpp render_impl; k_spawn's work from this lane's registers, spawn_rays.h): does
+    // the hit want a mirror ray?  (The parameters are read from device memory HERE: as kernel arguments they were loaded before
+    // the walk and their 22 scalar registers pushed the walk into scratch.)
+    F3 ks = f3(0.f, 0.f, 0.f);
+    bool wants_mirror = false;
+    if (spawn_dev && keep) {
+        const int mid = h.material_id;
+        const float* mats = spawn_dev->materials;
+        if (mid >= 0) ks = f3(mats[8 * mid + 3], mats[8 * mid + 4], mats[8 * mid + 5]);
+        wants_mirror = !(ks.z <= 0.01f) && spawn_dev->spawn;  // (:246 tests ks.z only; spawn = level + 1 < maxLevel, :267)
+    }
+    const unsigned long long m = __ballot(keep), mm = __ballot(wants_mirror);
     uint32_t* s_cnt = CGRT_BLOCK_SCRATCH(s_lds);
     const unsigned w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
+    if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m) | ((uint32_t)__popcll(mm) << 16);  // (a workgroup has at most 1024 lanes)
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
+        uint32_t tot = 0, mtot = 0;
         for (unsigned k = 0; k < nw; k++) {
             const uint32_t c = s_cnt[k];
-            s_cnt[k] = tot;
-            tot += c;
+            s_cnt[k] = tot | (mtot << 16);
+            tot += c & 0xffffu;
+            mtot += c >> 16;
         }
-        s_cnt[nw] = tot ? atomicAdd(count, tot) : 0u;
+        if (!tot) {
+            s_cnt[nw] = 0u;
+        } else if (spawn_dev) {
+            // count[0] = hits, count[1] = mirror rays, ONE 64-bit atomic for both: three more counters of their own (the shadow rays and
+            // hits of k_spawn's counter block, the mirror rays) quadrupled the same-line atomics and the Cornell frame's primary
+            // kernel went from 70 to 174 us.  (The level's shadow rays are hits x lights: no counter.)
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(count), (unsigned long long)tot | ((unsigned long long)mtot << 32));
+            s_cnt[nw] = (uint32_t)old;
+            s_lds[0] = (uint32_t)(old >> 32);  // (wave 0's stack: its walk is over)
+        } else {
+            s_cnt[nw] = atomicAdd(count, tot);
+        }
     }
     __syncthreads();
     if (keep) {
-        const unsigned long long idx = s_cnt[nw] + s_cnt[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long idx = s_cnt[nw] + (s_cnt[w] & 0xffffu) + (uint32_t)__popcll(m & below);
         float* r = rays + 7 * idx;
         r[0] = o.x;
         r[1] = o.y;
@@ -132,6 +156,22 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
         bool wr;
         (void)frame_pixel<QUAD>(F, px, py, pi, wr);
         pixels[idx] = py * F.W + px;
+        if (spawn_dev) {
+            // Entry idx's shadow ray towards light l is shadow ray idx * nlights + l (every entry of level 0 is a hit: no append).
+            const SpawnDev SP = *spawn_dev;
+            const F3 pointOn = add(o, scale(d, h.t));
+            for (unsigned l = 0; l < SP.nlights; l++) {
+                const unsigned long long q = idx * SP.nlights + l;
+                SP.sslot[q] = (int)q;
+                spawn_shadow_ray(SP.lights, l, pointOn, q, SP.srays, SP.sdist);
+            }
+            const uint32_t child = s_lds[0] + (s_cnt[w] >> 16) + (uint32_t)__popcll(mm & below);
+            if (wants_mirror) {
+                spawn_mirror_ray(pointOn, d, nn, child, SP.next_rays);
+                SP.next_pixels[child] = py * F.W + px;
+            }
+            SP.lvl[2 * idx + 1] = make_float4(ks.x, ks.y, ks.z, __int_as_float(wants_mirror ? (int)child : -1));
+        }
     }
 }
 // rgb of every pixel this rank owns := 0 (main.cpp:293; the hits are written over it afterwards)
@@ -192,10 +232,11 @@ __global__ CGRT_LB void k_trace_batch(SceneDev S, const float* __restrict__ rays
 // hits[i] therefore holds a hit that decides the test like the reference's own, not necessarily the closest one.
 template <bool COUNT, bool FAST, bool QUAD = false>
 __global__ CGRT_LB void k_trace_shadow(SceneDev S, const float* __restrict__ rays, const float* __restrict__ dist, unsigned long long n,
-                                       CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount, unsigned long long* counters, unsigned qrpw, unsigned adapt_max) {
+                                       CgrtHitDev* __restrict__ hits, const uint32_t* __restrict__ dcount, unsigned long long* counters, unsigned qrpw, unsigned adapt_max,
+                                       unsigned dmul) {
     extern __shared__ uint32_t s_lds[];
-    if (dcount) {
-        const unsigned long long present = *dcount;
+    if (dcount) {  // dmul: *dcount counts the entries whose shadow rays these are, dmul rays (lights) each
+        const unsigned long long present = (unsigned long long)*dcount * dmul;
         n = present < n ? present : n;
     }
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,12 +447,13 @@ static unsigned lane_grid(unsigned long long n, unsigned block, unsigned rpw, un
     return grid_for(n, rpw < 64u ? rpw : block);
 }
 hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
-                              unsigned long long* counters, hipStream_t stream, const uint32_t* dcount) {
+                              unsigned long long* counters, hipStream_t stream, const uint32_t* dcount, unsigned long long expected) {
     if (n == 0) return hipSuccess;
     const unsigned block = (unsigned)trace_block(S);
     const bool fast = S.fast_root != REF_NONE;
-    const unsigned adapt = list_adapt_max(S, dcount);
-    const int shape = adapt ? SHAPE_LANE64 : list_shape(S, n);
+    // expected (with dcount): the host's estimate of the device count picks the shape, as an exact length would
+    const unsigned adapt = expected ? 0u : list_adapt_max(S, dcount);
+    const int shape = adapt ? SHAPE_LANE64 : list_shape(S, expected ? expected : n);
     if (shape == SHAPE_QUAD16 || shape == SHAPE_QUAD4) {
         const unsigned q = shape == SHAPE_QUAD4 ? 4u : 16u;
         if (counters)
@@ -429,44 +471,46 @@ hipError_t launch_trace_batch(const SceneDev& S, const float* rays, unsigned lon
     return hipGetLastError();
 }
 hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
-                               const uint32_t* dcount, unsigned long long* counters) {
+                               const uint32_t* dcount, unsigned long long* counters, unsigned long long expected, unsigned dmul) {
     if (n == 0) return hipSuccess;
     const unsigned block = (unsigned)trace_block(S);
     const bool fast = S.fast_root != REF_NONE;
-    const unsigned adapt = list_adapt_max(S, dcount);
-    const int shape = adapt ? SHAPE_LANE64 : list_shape(S, n);
+    const unsigned adapt = expected ? 0u : list_adapt_max(S, dcount);
+    const int shape = adapt ? SHAPE_LANE64 : list_shape(S, expected ? expected : n);
     if (shape == SHAPE_QUAD16 || shape == SHAPE_QUAD4) {
         const unsigned q = shape == SHAPE_QUAD4 ? 4u : 16u;
         if (counters)
-            CGRT_LAUNCHQ(k_trace_shadow, true, grid_for(n, q), stream, S, rays, dist, n, hits, dcount, counters, q, 0u);
+            CGRT_LAUNCHQ(k_trace_shadow, true, grid_for(n, q), stream, S, rays, dist, n, hits, dcount, counters, q, 0u, dmul ? dmul : 1u);
         else
-            CGRT_LAUNCHQ(k_trace_shadow, false, grid_for(n, q), stream, S, rays, dist, n, hits, dcount, counters, q, 0u);
+            CGRT_LAUNCHQ(k_trace_shadow, false, grid_for(n, q), stream, S, rays, dist, n, hits, dcount, counters, q, 0u, dmul ? dmul : 1u);
         return hipGetLastError();
     }
     const unsigned rpw = shape == SHAPE_LANE16 ? 16u : 64u;
     const unsigned grid = lane_grid(n, block, rpw, adapt);
     if (counters)
-        CGRT_LAUNCH2(k_trace_shadow, true, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt);
+        CGRT_LAUNCH2(k_trace_shadow, true, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt, dmul ? dmul : 1u);
     else
-        CGRT_LAUNCH2(k_trace_shadow, false, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt);
+        CGRT_LAUNCH2(k_trace_shadow, false, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt, dmul ? dmul : 1u);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
-                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters, float* rgb) {
+                                        int* pixels, uint32_t* count, hipStream_t stream, unsigned long long* counters, float* rgb,
+                                        const SpawnDev* spawn) {
+    const SpawnDev* SP = spawn;  // (a DEVICE address)
     if (F.nblocks == 0) return hipSuccess;
     const unsigned block = (unsigned)F.block;
     const bool fast = S.fast_root != REF_NONE;
     if (F.block == 64 && quad_shape_for(S, (unsigned long long)F.nblocks * 64ull)) {
         if (counters)
-            CGRT_LAUNCHQ(k_trace_primary_compact, true, 4u * F.nblocks, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
+            CGRT_LAUNCHQ(k_trace_primary_compact, true, 4u * F.nblocks, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb, SP);
         else
-            CGRT_LAUNCHQ(k_trace_primary_compact, false, 4u * F.nblocks, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
+            CGRT_LAUNCHQ(k_trace_primary_compact, false, 4u * F.nblocks, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb, SP);
         return hipGetLastError();
     }
     if (counters)
-        CGRT_LAUNCH2(k_trace_primary_compact, true, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
+        CGRT_LAUNCH2(k_trace_primary_compact, true, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb, SP);
     else
-        CGRT_LAUNCH2(k_trace_primary_compact, false, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb);
+        CGRT_LAUNCH2(k_trace_primary_compact, false, fast, F.nblocks, block, stream, S, C, F, rays, hits, normals, pixels, count, counters, rgb, SP);
     return hipGetLastError();
 }
 hipError_t launch_clear_owned(const FrameDev& F, float* rgb, hipStream_t stream) {

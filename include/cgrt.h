@@ -124,6 +124,14 @@ int cgrt_set_primary_mode(int mode);
  * max_rays = 0 keeps the current threshold.  Process-wide. */
 int cgrt_set_kernel_shape(int mode, uint64_t max_rays);
 int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays);
+/* cgrt_render*: 1 (default) = a frame of the same shape (size, rank, depth, light count) as the scene's previous one is issued in one
+ * go, its launches sized from what that frame found per level, the counts checked once behind the frame (and the frame drawn again
+ * the exact way when a list outgrew its launch); 0 = every frame waits for the device's hit count before it sizes the lists, as the
+ * first frame always does.  The pixels are identical (tested); only the host round trips inside the frame differ.  Process-wide. */
+int cgrt_set_render_prediction(int enabled);
+/* How the scene's last cgrt_render* frame was drawn: 0 = exactly sized, 1 = as predicted, 2 = predicted, a list outgrew its launch,
+ * drawn again exactly; -1 for a NULL scene.  (Tests, diagnostics.) */
+int cgrt_debug_render_path(const CgrtScene* scene);
 /* Certified walk (no counterpart upstream; DESIGN.md "Certified walk").  The exact walk takes every step of the
  * reference's ordered descent (bvh.cpp:572-758) because its culling quirks are part of the result.  A scene may also
  * carry a "fast tree" (a 4-wide tree over the reference LEAVES) and per-leaf box paths: a ray then searches the fast
