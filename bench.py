@@ -372,6 +372,11 @@ def main():
                 best = st
         wall = time.perf_counter() - t_start
         rays = best["primary_rays"] + best["shadow_rays"] + best["reflection_rays"]
+        path = scene.last_render_path()
+        # the same frame drawn the exact way (what a first frame, a resized frame or a frame after a camera jump costs): after the timed region
+        pkg.set_render_prediction(False)
+        exact_ms = min(scene.render(cam, W, H, max_level=2)[1]["device_ms"] for _ in range(max(3, args.steps // 4)))
+        pkg.set_render_prediction(True)
         _, _, work = scene.render_counted(cam, W, H, max_level=2)  # instrumented frame, outside the timed region
         parts = {k: algorithmic_bytes(v, rs) for k, v in work.items()}
         alg_bytes = sum(parts.values())
@@ -391,7 +396,12 @@ def main():
             "config": {"workload": f"{scene_name}, {W}x{H}, cgrt_render depth 2 ({walk} walk): {best['primary_rays']} primary, "
                                    f"{best['shadow_rays']} shadow, {best['reflection_rays']} mirror rays",
                        "timing": "ms_per_step: HIP events around all kernels of the best frame (device side of cgrt_render); "
-                                 f"host-inclusive mean {wall / args.steps * 1e3:.3f} ms (RGB download included)"},
+                                 f"host-inclusive mean {wall / args.steps * 1e3:.3f} ms (RGB download included)",
+                       "frame_path": {0: "exactly sized (the host waits for the device's hit count inside the frame)",
+                                      1: "predicted: every launch issued at once, sized from the previous frame of the same shape, counts checked behind the frame "
+                                         "(cgrt_set_render_prediction; same pixels, tests/test_render_prediction_gpu.py)",
+                                      2: "predicted, outgrown, drawn again exactly"}.get(path, str(path)),
+                       "exactly_sized_frame_ms": round(exact_ms, 4)},
             "roofline": {
                 "bound": "hbm",
                 "bound_note": "classification of SURVEY.md 8(d); like the primary kernel these batches are latency-bound (their time is the time of their hardest rays), see profiles/",
