@@ -106,7 +106,7 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/cgrt.h declares
 EXPORTS = [
-    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_kernel_shape", "cgrt_get_kernel_shape", "cgrt_set_render_prediction", "cgrt_debug_render_path", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_scene_build_info", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
+    "cgrt_scene_create", "cgrt_scene_destroy", "cgrt_set_leaf_accel", "cgrt_num_subnodes", "cgrt_set_primary_mode", "cgrt_set_kernel_shape", "cgrt_get_kernel_shape", "cgrt_set_render_prediction", "cgrt_set_frame_hints", "cgrt_debug_set_hint_thresholds", "cgrt_debug_hint_counts", "cgrt_debug_render_path", "cgrt_set_fast_tree", "cgrt_scene_set_walk", "cgrt_scene_walk", "cgrt_scene_build_info", "cgrt_num_levels", "cgrt_num_nodes", "cgrt_get_nodes", "cgrt_leaf_prims",
     "cgrt_build_seconds", "cgrt_device_bytes", "cgrt_intersect_batch", "cgrt_set_call_combining", "cgrt_debug_combiner_stats", "cgrt_intersect_brute_batch", "cgrt_intersect_batch_device", "cgrt_trace_primary",
     "cgrt_trace_primary_device", "cgrt_generate_rays", "cgrt_render", "cgrt_render_soft", "cgrt_render_mapped", "cgrt_render_rank", "cgrt_render_counted", "cgrt_trace_primary_multi", "cgrt_render_multi", "cgrt_count_primary", "cgrt_count_batch", "cgrt_debug_wave_times", "cgrt_debug_fastdiv_check", "cgrt_debug_gather_calibration", "cgrt_debug_check_layout", "cgrt_debug_layout_hash", "cgrt_set_build_threads", "cgrt_record_sizes",
     "cgrt_ray_triangle_batch", "cgrt_ray_plane_batch", "cgrt_ray_box_batch", "cgrt_ray_sphere_batch",
@@ -143,6 +143,8 @@ def lib() -> C.CDLL:
     L.cgrt_set_fast_tree.argtypes = [i32]
     L.cgrt_set_kernel_shape.argtypes = [i32, u64]
     L.cgrt_set_render_prediction.argtypes = [i32]
+    L.cgrt_set_frame_hints.argtypes = [i32]
+    L.cgrt_debug_set_hint_thresholds.argtypes = [u32, u32]
     L.cgrt_debug_render_path.argtypes = [C.c_void_p]
     L.cgrt_get_kernel_shape.argtypes = [C.POINTER(i32), C.POINTER(u64)]
     L.cgrt_scene_set_walk.argtypes = [vp, i32]
@@ -244,6 +246,15 @@ def set_kernel_shape(mode: int = -1, max_rays: int = 0) -> None:
     _check(lib().cgrt_set_kernel_shape(int(mode), int(max_rays)))
 
 
+def set_frame_hints(mode: int = -1) -> None:
+    """Primary frames: -1 by frame size, 0 off, 1 the previous frame's hard tiles first, 2 hard tiles as four 16-ray waves; same pixels."""
+    _check(lib().cgrt_set_frame_hints(int(mode)))
+
+
+def debug_set_hint_thresholds(dense_ticks: int = 0, sparse_ticks: int = 0) -> None:
+    _check(lib().cgrt_debug_set_hint_thresholds(int(dense_ticks), int(sparse_ticks)))
+
+
 def set_render_prediction(enabled: bool = True) -> None:
     """cgrt_render*: size a frame's launches from the scene's previous frame of the same shape (default) or wait for the device's
     counts inside every frame; same pixels."""
@@ -316,6 +327,12 @@ class Scene:
     def __del__(self) -> None:
         if lib is not None and C is not None:  # module globals are already gone when the interpreter is shutting down
             self.close()
+
+    def hint_counts(self):
+        """Lengths of the three rotating hard lists of the primary frames' hints (diagnostics)."""
+        out = (C.c_uint32 * 3)()
+        _check(lib().cgrt_debug_hint_counts(self._h, out))
+        return [int(v) for v in out]
 
     def last_render_path(self) -> int:
         """0 = the last render() sized every list exactly, 1 = drawn as the previous frame predicted, 2 = predicted, too small, drawn again."""

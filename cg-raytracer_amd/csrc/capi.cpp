@@ -42,6 +42,8 @@ std::mutex g_options_mutex;
 BuildOptions g_build_options;
 std::atomic<int> g_call_combining{1};  // cgrt_set_call_combining
 std::atomic<int> g_render_predict{1};  // cgrt_set_render_prediction
+std::atomic<int> g_frame_hints{-1};    // cgrt_set_frame_hints: -1 auto, 0 off, 1 hard tiles first, 2 hard tiles 16 rays per wave
+std::atomic<unsigned> g_hint_thr_dense{0}, g_hint_thr_sparse{0};  // cgrt_debug_set_hint_thresholds (0: the defaults)
 std::atomic<int> g_primary_mode{0};  // 0 = one wave per tile, 1 = persistent waves with lane refill
 
 int fail(int code, const std::string& msg) {
@@ -125,6 +127,8 @@ bool make_frame(int W, int H, int x0, int y0, int x1, int y1, int rank, int nran
     F.block = block;
     F.nblocks = ((F.nst_rank + 7u) / 8u) * 8u * (64u / ((uint32_t)block / 64u));
     F.packed = 0;
+    F.hint = nullptr;
+    F.hint_blocks = F.hint_rgen = F.hint_wgen = 0;
     return true;
 }
 
@@ -166,6 +170,27 @@ struct CgrtScene {
     // launch that used it last (an event per block), so any number of frames may be in flight on any streams
     std::mutex queue_mutex;
     unsigned launch_seq = 0;
+    // Frame hints (cgrt_layout.h HintDev; attach_hints below): the hard-tile lists a primary frame leaves for the next frame of
+    // the same shape.  Guarded by hints_mutex while a launch is being issued; the buffers themselves are only touched by kernels.
+    struct FrameHints {
+        std::mutex mu;
+        bool ready = false;           // buffers allocated for `key`
+        int key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // W, H, x0, y0, x1, y1, rank, nranks
+        int per_tile = 0;             // 1 / 4 (the policy the buffers were made for)
+        unsigned thr[2] = {0, 0};     // the thresholds in the device structs
+        uint32_t cap = 0;
+        void* mem = nullptr;          // 3 x {flag[ntiles], list[cap], count} + 3 HintDev
+        size_t mem_bytes = 0;
+        HintDev* phase[3] = {nullptr, nullptr, nullptr};  // device addresses
+        HintDev phase_host[3];        // what they hold
+        uint64_t seq = 0;             // frames issued with these buffers
+        bool have_prev = false;       // the set this frame would read was written by frame seq - 1
+        hipStream_t last_stream = nullptr;
+        bool last_stream_valid = false;
+        hipStream_t hint_stream = nullptr;  // the stream of the last launch that used the buffers
+        bool hint_stream_valid = false;
+        int cooldown = 0;             // frames to run without hints after the caller changed streams
+    } hints;
     hipEvent_t queue_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // Host-pointer entries (cgrt_intersect_batch, cgrt_trace_primary, cgrt_count_*, ...) run on "call lanes": a private
     // stream + device scratch + pinned staging + a counter block, taken from this pool for the duration of one call and
@@ -274,7 +299,7 @@ struct CgrtScene {
     ~CgrtScene() {
         if (device < 0) return;
         (void)hipSetDevice(device);
-        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues})
+        for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues, hints.mem})
             if (p) (void)hipFree(p);
         if (pin_frame) (void)hipHostFree(pin_frame);
         for (hipEvent_t e : {raux.spawned, raux.traced, raux.e0, raux.e1, raux.primary_done})
@@ -1149,6 +1174,27 @@ int cgrt_debug_combiner_stats(const CgrtScene* s, uint64_t* out4) {  // (five wo
     return CGRT_OK;
 }
 int cgrt_debug_render_path(const CgrtScene* s) { return s ? s->rpred.last_path : -1; }
+int cgrt_debug_hint_counts(CgrtScene* s, uint32_t* out3) {  // the three hard lists' lengths (after a device synchronise): diagnostics
+    if (!s || !out3) return fail(CGRT_E_ARG, "NULL argument");
+    NEED_DEVICE(s);
+    std::lock_guard<std::mutex> lk(s->hints.mu);
+    out3[0] = out3[1] = out3[2] = 0;
+    if (!s->hints.ready) return CGRT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int k = 0; k < 3; k++) HIP_TRY(hipMemcpy(out3 + k, s->hints.phase_host[k].count_r, 4, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+int cgrt_debug_set_hint_thresholds(unsigned dense_ticks, unsigned sparse_ticks) {
+    g_hint_thr_dense.store(dense_ticks);
+    g_hint_thr_sparse.store(sparse_ticks);
+    return CGRT_OK;
+}
+int cgrt_set_frame_hints(int mode) {
+    if (mode < -1 || mode > 2) return fail(CGRT_E_ARG, "frame hint mode: -1 auto, 0 off, 1 hard tiles first, 2 hard tiles 16 rays per wave");
+    g_frame_hints.store(mode);
+    return CGRT_OK;
+}
 int cgrt_set_render_prediction(int enabled) {
     g_render_predict.store(enabled ? 1 : 0);
     return CGRT_OK;
@@ -1227,8 +1273,132 @@ int cgrt_intersect_brute_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, in
     return CGRT_OK;
 }
 
-static int launch_primary(CgrtScene* s, const CameraDev& C, const FrameDev& F, CgrtHitDev* d_hits, float* d_normals, unsigned long long* counters,
+// Frame hints: which regime a frame is in goes by its size (profiles/r3_frame_hints.txt, dragon stand-in): frames of up to ~1.3 M
+// rays (960x540, a 1/8 share of the 4K frame) are as long as their longest wave -- their hard tiles are traced 16 rays per wave
+// (960x540 81 -> 63 us, the slowest 1/8 share 92 -> 79 us); a rank's share of up to ~2.6 M rays (a 1/4 share) gains from tracing
+// its hard tiles first in the usual 64-ray waves (118 -> 108 us); a whole frame of that size does not (1080p: 115.4 -> 118.2 us),
+// and larger frames gain nothing: no hints for them.  cgrt_set_frame_hints forces a mode; CGRT_FRAME_HINTS likewise (experiments).
+#ifndef CGRT_HINT_SPARSE_MAX_RAYS
+#define CGRT_HINT_SPARSE_MAX_RAYS 1300000ull
+#endif
+#ifndef CGRT_HINT_FIRST_MAX_RAYS
+#define CGRT_HINT_FIRST_MAX_RAYS 2600000ull
+#endif
+#ifndef CGRT_HINT_THR_DENSE
+#define CGRT_HINT_THR_DENSE 4500u  // 45 us of s_memrealtime (swept: profiles/r3_frame_hints.txt)
+#endif
+#ifndef CGRT_HINT_THR_SPARSE
+#define CGRT_HINT_THR_SPARSE 2500u  // a 16-ray wave of a hard tile (64 hard rays: 97 us as one wave, 51 us as four)
+#endif
+static int hint_mode_for(const FrameDev& F) {
+    static const int env = [] {
+        const char* e = getenv("CGRT_FRAME_HINTS");
+        return e ? atoi(e) : -2;
+    }();
+    const int m = env >= -1 ? env : g_frame_hints.load();
+    if (m >= 0) return m > 2 ? 0 : m;
+    const unsigned long long rays = owned_pixels(F);
+    if (rays <= CGRT_HINT_SPARSE_MAX_RAYS) return 2;
+    if (rays <= CGRT_HINT_FIRST_MAX_RAYS && F.nranks > 1) return 1;
+    return 0;
+}
+// Attaches the scene's hint buffers to F for ONE launch on `stream` (or leaves F without hints).  Called with s->hints.mu held
+// until the launch has been issued.  What keeps the buffers consistent: a frame reads the set the previous frame wrote, writes the
+// next and zeroes the counter of the third -- so frames that use them must run one after the other.  Frames issued on one stream
+// do.  When the caller changes streams, frames run WITHOUT hints (they touch no buffer) for a few launches, and before hints are
+// taken up again the stream that used them last is waited for (it has long finished).
+static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
+    CgrtScene::FrameHints& Hs = s->hints;
+    const int mode = (F.block == 64 && !F.packed && s->dev.fast_root != REF_NONE) ? hint_mode_for(F) : 0;
+    if (Hs.last_stream_valid && stream != Hs.last_stream) {
+        Hs.cooldown = 8;
+        Hs.have_prev = false;
+    }
+    const hipStream_t prev_stream = Hs.last_stream;
+    const bool prev_valid = Hs.last_stream_valid;
+    Hs.last_stream = stream;
+    Hs.last_stream_valid = true;
+    if (mode == 0) {
+        Hs.have_prev = false;
+        return CGRT_OK;
+    }
+    if (Hs.cooldown > 0) {
+        if (--Hs.cooldown > 0) return CGRT_OK;
+        if (prev_valid) (void)hipStreamSynchronize(prev_stream);  // (a destroyed stream answers with an error: nothing of ours is on it then)
+        if (Hs.hint_stream_valid && Hs.hint_stream != stream) (void)hipStreamSynchronize(Hs.hint_stream);
+        (void)hipGetLastError();
+    }
+    const int key[8] = {F.W, F.H, F.x0, F.y0, F.x1, F.y1, F.rank, F.nranks};
+    const int per_tile = mode == 2 ? 4 : 1;
+    const uint32_t ntiles = (uint32_t)F.tiles_x * (uint32_t)F.tiles_y;
+    const unsigned td = g_hint_thr_dense.load(), ts = g_hint_thr_sparse.load();
+    const unsigned thr[2] = {td ? td : CGRT_HINT_THR_DENSE, ts ? ts : CGRT_HINT_THR_SPARSE};
+    if (!Hs.ready || std::memcmp(key, Hs.key, sizeof(key)) != 0 || Hs.per_tile != per_tile || thr[0] != Hs.thr[0] || thr[1] != Hs.thr[1]) {
+        // (re)build the buffers: only when the frame's shape changes.  Whatever used the old ones must have finished.
+        if (Hs.hint_stream_valid) (void)hipStreamSynchronize(Hs.hint_stream);
+        (void)hipGetLastError();
+        const uint64_t owned_tiles = (owned_pixels(F) + 63) / 64;
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(0xfffeu, std::max<uint64_t>(64, owned_tiles / 8));  // (a 40 us wave is rarer than that)
+        const size_t set_words = (size_t)ntiles + cap + 16;  // flag | list | count (+ padding)
+        const size_t bytes = 3 * set_words * 4 + 3 * 256;
+        if (Hs.mem_bytes < bytes) {
+            if (Hs.mem) (void)hipFree(Hs.mem);
+            Hs.mem = nullptr;
+            Hs.mem_bytes = 0;
+            HIP_TRY(hipMalloc(&Hs.mem, bytes));
+            Hs.mem_bytes = bytes;
+        }
+        HIP_TRY(hipMemsetAsync(Hs.mem, 0, bytes, stream));  // (generation 0 is never used: every flag is stale; on the launch's stream: ordered before it)
+        uint32_t* base = static_cast<uint32_t*>(Hs.mem);
+        char* structs = reinterpret_cast<char*>(base + 3 * set_words);
+        auto flag = [&](int k) { return base + (size_t)k * set_words; };
+        auto list = [&](int k) { return flag(k) + ntiles; };
+        auto count = [&](int k) { return list(k) + cap; };
+        for (int p = 0; p < 3; p++) {
+            HintDev h{};
+            const int r = p, w = (p + 1) % 3, z = (p + 2) % 3;
+            h.flag_r = flag(r), h.list_r = list(r), h.count_r = count(r);
+            h.flag_w = flag(w), h.list_w = list(w), h.count_w = count(w);
+            h.count_z = count(z);
+            h.cap = cap;
+            h.per_tile = (uint32_t)per_tile;
+            h.thr_dense = thr[0];
+            h.thr_sparse = thr[1];
+            h.thr_min = std::min(thr[0], thr[1]) - (std::min(thr[0], thr[1]) >> 2);
+            Hs.phase[p] = reinterpret_cast<HintDev*>(structs + 256 * p);
+            Hs.phase_host[p] = h;
+            HIP_TRY(hipMemcpyAsync(Hs.phase[p], &h, sizeof(h), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+        }
+        std::memcpy(Hs.key, key, sizeof(key));
+        Hs.per_tile = per_tile;
+        Hs.thr[0] = thr[0], Hs.thr[1] = thr[1];
+        Hs.cap = cap;
+        Hs.seq = 0;
+        Hs.have_prev = false;
+        Hs.ready = true;
+    }
+    const uint64_t seq = Hs.seq++;
+    auto gen_of = [](uint64_t q) { return (uint32_t)(q % 65535u) + 1u; };
+    F.hint = Hs.phase[seq % 3];
+    F.hint_blocks = Hs.cap * (uint32_t)per_tile;
+    F.hint_rgen = Hs.have_prev ? gen_of(seq - 1) : 0u;
+    F.hint_wgen = gen_of(seq);
+    Hs.have_prev = true;
+    Hs.hint_stream = stream;
+    Hs.hint_stream_valid = true;
+    return CGRT_OK;
+}
+
+static int launch_primary(CgrtScene* s, const CameraDev& C, const FrameDev& F_in, CgrtHitDev* d_hits, float* d_normals, unsigned long long* counters,
                           hipStream_t stream) {
+    FrameDev F = F_in;
+    if (g_primary_mode.load() == 0 && !counters) {  // (the instrumented and the persistent kernels take no hints)
+        std::lock_guard<std::mutex> lk(s->hints.mu);
+        const int rc = attach_hints(s, F, stream);
+        if (rc) return rc;
+        HIP_TRY(launch_trace_primary(s->dev, C, F, d_hits, d_normals, counters, stream));
+        return CGRT_OK;
+    }
     if (g_primary_mode.load() == 1) {
         std::lock_guard<std::mutex> lk(s->queue_mutex);
         const unsigned k = s->launch_seq++ & 7u;

@@ -158,6 +158,29 @@ struct CameraDev {
 // the round-robin workgroup->XCD placement observed on MI355X) by ONE XCD, whose 4 MiB L2 then holds
 // that screen region's nodes and triangles instead of sharing every region with the 7 other L2s.
 // Placement is a speed matter only: results do not depend on it.
+// Frame hints (trace_kernels.hip "frame hints", capi.cpp FrameHints): what the previous frame of the same shape
+// learnt about its tiles, for the next one.  Every wave measures its own wall time; a wave that took long puts its 8x8 tile on the
+// frame's HARD LIST.  The next frame traces the tiles of that list FIRST (its first cap * per_tile workgroups; the regular
+// workgroups skip them) -- in the same 64-ray waves (per_tile = 1: the long waves no longer start in the frame's last round), or,
+// for small frames whose time is the time of their longest wave, as four waves of 16 rays (per_tile = 4: the quad tail from the
+// first step, two tile rows each).  Only the order and the layout change: every owned pixel is traced exactly once, by the hard
+// workgroup iff the pair (list slot i, flag of the tile) is consistent -- list[i] == tile and flag[tile] == generation << 16 | i + 1
+// -- which both kinds of workgroup evaluate on the same read-only memory.  Three sets rotate: a frame reads one, writes the next
+// and zeroes the counter of the third; the generation stamp makes stale flags harmless without clearing them.
+struct HintDev {  // one per rotation phase, resident in device memory
+    const uint32_t* flag_r;  // per tile: generation << 16 | slot + 1 (what the previous frame left)
+    const uint32_t* list_r;  // hard tiles (tile = ty * tiles_x + tx)
+    const uint32_t* count_r;
+    uint32_t* flag_w;        // what this frame leaves
+    uint32_t* list_w;
+    uint32_t* count_w;
+    uint32_t* count_z;       // the third set's counter, zeroed by this frame
+    uint32_t cap;            // tiles a list holds (<= 0xfffe)
+    uint32_t per_tile;       // workgroups per hard tile: 1 or 4
+    uint32_t thr_dense, thr_sparse;  // s_memrealtime ticks (100 MHz) from which a 64-ray / 16-ray wave counts as hard
+    uint32_t thr_min;        // no wave faster than this can be hard: it ends without looking any further
+};
+
 struct FrameDev {
     int W, H;
     int x0, y0, x1, y1;
@@ -169,6 +192,10 @@ struct FrameDev {
     uint32_t nblocks;      // workgroups launched: 64 / (block / 64) per super-tile, super-tiles padded to 8
     int packed;            // 1: results are written at blockIdx * block + threadIdx (the rank's pixels back to back, in the kernel's
                            // own order: one contiguous download per device) instead of at y * W + x
+    const HintDev* hint;   // nullptr: no hints (the workgroups map to the tiles in launch order)
+    uint32_t hint_blocks;  // cap * per_tile workgroups in FRONT of the nblocks regular ones
+    uint32_t hint_rgen;    // generation of the set to read (0: nothing to read -- a first frame still writes)
+    uint32_t hint_wgen;    // generation this frame stamps on what it writes
 };
 static const int ST_TILES = 8;  // tiles per super-tile side
 // Workgroups of the traversal kernels hold 64, 128 or 256 threads (chosen per launch: FrameDev::block, blockDim.x): one wave

@@ -40,14 +40,24 @@ __device__ __forceinline__ bool frame_pixel(const FrameDev& F, int& x, int& y, s
     return tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y);
 }
 
-template <bool COUNT, bool FAST, bool QUAD = false>
+// HINT: the launch carries frame hints (cgrt_layout.h HintDev) -- an instantiation of its own, so that the plain frame kernel is the
+// kernel it was (the hint code costs every launch a few percent when it is merely compiled in: measured).
+template <bool COUNT, bool FAST, bool QUAD = false, bool HINT = false>
 __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, CgrtHitDev* __restrict__ hits, float* __restrict__ normals,
                                         unsigned long long* counters) {
     extern __shared__ uint32_t s_lds[];  // CGRT_LDS_WORDS(blockDim.x): stacks, quad-tail owner maps, workgroup scratch
     int x = 0, y = 0;
     size_t pidx;
     bool writer;
-    const bool active = frame_pixel<QUAD>(F, x, y, pidx, writer);
+    bool active;
+    if (HINT && F.hint) {  // (the run-time test is redundant; with it the compiler keeps the walk out of scratch)
+        pidx = 0;          // (hinted frames are never packed)
+        writer = true;
+        active = hinted_tile_pixel(F, x, y, CGRT_HINT_SCRATCH(s_lds));
+    } else {
+        if (HINT && (threadIdx.x & 63u) == 0u) CGRT_HINT_SCRATCH(s_lds)[1] = 0xffffffffu;  // nothing for hint_finish
+        active = frame_pixel<QUAD>(F, x, y, pidx, writer);
+    }
     LaneCounters cnt;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     if (active) primary_ray(C, F.W, F.H, x, y, o, d);
@@ -62,6 +72,7 @@ __global__ CGRT_LB void k_trace_primary(SceneDev S, CameraDev C, FrameDev F, Cgr
         finish_ray(S, o, d, t, hit_rec, hits + pix, normals ? normals + 3 * pix : nullptr);
     }
     if (COUNT) flush_counters(cnt, active && writer, counters);
+    if (HINT) hint_finish(CGRT_HINT_SCRATCH(s_lds));
 }
 
 // Primary frame for the shading wavefront (cgrt_render): the fused kernel's walk, but only the rays that HIT are written,
@@ -433,6 +444,11 @@ hipError_t launch_trace_primary(const SceneDev& S, const CameraDev& C, const Fra
             CGRT_LAUNCHQ(k_trace_primary, true, 4u * F.nblocks, stream, S, C, F, hits, normals, counters);
         else
             CGRT_LAUNCHQ(k_trace_primary, false, 4u * F.nblocks, stream, S, C, F, hits, normals, counters);
+        return hipGetLastError();
+    }
+    if (F.hint && fast && F.block == 64 && !counters) {  // frame hints: the hard list's workgroups come first
+        hipLaunchKernelGGL((k_trace_primary<false, true, false, true>), dim3(F.nblocks + F.hint_blocks), dim3(64), lds_bytes(64), stream, S, C, F, hits,
+                           normals, counters);
         return hipGetLastError();
     }
     if (counters)

@@ -42,7 +42,9 @@ namespace cgrt {
 #define CGRT_STACK_SLOTS (2 * (MAX_LEVELS - 1) + SUB_STACK_ENTRIES)
 // Dynamic LDS of a traversal kernel launched with `block` threads: the waves' stacks, then 16 words per wave for the quad
 // tail's owner map (walk_fast.h), then block / 64 + 1 words of workgroup scratch.
-#define CGRT_LDS_WORDS(block) ((block) * CGRT_STACK_SLOTS + ((block) / 64) * 16 + (block) / 64 + 1)
+#define CGRT_LDS_WORDS(block) ((block) * CGRT_STACK_SLOTS + ((block) / 64) * 16 + (block) / 64 + 1 + CGRT_HINT_WORDS)
+#define CGRT_HINT_WORDS 6  // a hinted frame's wave keeps what hint_finish needs here (not in registers through the walk)
+#define CGRT_HINT_SCRATCH(lds) (CGRT_BLOCK_SCRATCH(lds) + (blockDim.x >> 6) + 1)
 // this wave's stack region / owner map inside the dynamic LDS array `lds`
 #define CGRT_WAVE_STACK(lds) ((lds) + (threadIdx.x >> 6) * (CGRT_STACK_SLOTS * 64))
 #define CGRT_WAVE_MAP(lds) ((lds) + blockDim.x * CGRT_STACK_SLOTS + (threadIdx.x >> 6) * 16)
@@ -768,6 +770,107 @@ __device__ __forceinline__ bool tile_pixel_of(const FrameDev& F, const uint32_t 
     y = F.y0 + ty * 8 + (lane >> 3);
     return x < F.x1 && y < F.y1;
 }
+// ---- frame hints (cgrt_layout.h HintDev) ----
+// What hint_finish needs is parked in the workgroup's LDS (CGRT_HINT_SCRATCH; hinted launches have single-wave workgroups) by lane
+// 0: carried in scalar registers through the walk it cost the frame kernel 12 B of scratch.
+//   [0] s_memrealtime at the wave's start (low word)   [1] tile | hard << 31, 0xffffffff: the wave traces nothing (or no hints)
+//   [2] generation to stamp   [3], [4] the HintDev's address   [5] the time below which no wave is hard
+__device__ __forceinline__ void hint_park(uint32_t* s_hint, uint32_t t0, uint32_t tile_hard, uint32_t wgen, const HintDev* Hn, uint32_t thr_min) {
+    if ((threadIdx.x & 63u) == 0u) {
+        s_hint[0] = t0;
+        s_hint[1] = tile_hard;
+        s_hint[2] = wgen;
+        s_hint[3] = (uint32_t)(uintptr_t)Hn;
+        s_hint[4] = (uint32_t)((uintptr_t)Hn >> 32);
+        s_hint[5] = thr_min;
+    }
+}
+// The pixel of this lane in a hinted launch of single-wave workgroups.
+__device__ __forceinline__ bool hinted_tile_pixel(const FrameDev& F, int& x, int& y, uint32_t* s_hint) {
+    const HintDev* __restrict__ Hn = F.hint;
+    const uint32_t* __restrict__ flag_r = Hn->flag_r;
+    const uint32_t* __restrict__ list_r = Hn->list_r;
+    uint32_t b = blockIdx.x;
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if (b == 0 && threadIdx.x == 0) *Hn->count_z = 0u;
+    const uint32_t cap = Hn->cap, per = Hn->per_tile;
+    uint32_t nh = 0;
+    if (F.hint_rgen) {
+        nh = *Hn->count_r;
+        nh = nh < cap ? nh : cap;
+    }
+    const uint32_t ntiles = (uint32_t)F.tiles_x * (uint32_t)F.tiles_y;
+    uint32_t tile = 0xffffffffu;
+    bool in = false;
+    if (b < F.hint_blocks) {  // a workgroup of the hard list
+        const uint32_t i = per == 4u ? (b >> 2) : b, q = per == 4u ? (b & 3u) : 0u;
+        if (i < nh) {
+            const uint32_t cand = list_r[i];
+            if (cand < ntiles && flag_r[cand] == ((F.hint_rgen << 16) | (i + 1u))) {  // (else not a consistent pair: the regular workgroup traces it)
+                tile = cand | 0x80000000u;
+                const int tx = (int)(cand % (uint32_t)F.tiles_x), ty = (int)(cand / (uint32_t)F.tiles_x);
+                x = F.x0 + tx * 8 + (lane & 7);
+                y = F.y0 + ty * 8 + (per == 4u ? 2 * (int)q : 0) + (lane >> 3);  // 16 rays per wave: tile rows 2q and 2q + 1 on lanes 0..15
+                in = (per != 4u || lane < 16) && x < F.x1 && y < F.y1;
+            }
+        }
+    } else {  // a regular workgroup: tile_pixel_of's mapping for single-wave workgroups
+        b -= F.hint_blocks;
+        const uint32_t lane8 = b & 7u, j = b >> 3;
+        const uint32_t s = (j >> 6) * 8u + lane8;  // rank-local super-tile
+        const uint32_t st = (uint32_t)F.rank + (uint32_t)F.nranks * s;
+        const int stx = (int)(st % (uint32_t)F.st_x), sty = (int)(st / (uint32_t)F.st_x);
+        const int idx = (int)(j & 63u);
+        const int tx = stx * ST_TILES + (idx & 7), ty = sty * ST_TILES + (idx >> 3);
+        if (s < F.nst_rank && tx < F.tiles_x && ty < F.tiles_y) {
+            const uint32_t cand = (uint32_t)ty * (uint32_t)F.tiles_x + (uint32_t)tx;
+            bool taken = false;
+            if (F.hint_rgen) {
+                const uint32_t v = flag_r[cand], slot = v & 0xffffu;
+                taken = (v >> 16) == F.hint_rgen && slot != 0u && slot - 1u < nh && list_r[slot - 1u] == cand;  // a hard workgroup has it
+            }
+            if (!taken) {
+                tile = cand;
+                x = F.x0 + tx * 8 + (lane & 7);
+                y = F.y0 + ty * 8 + (lane >> 3);
+                in = x < F.x1 && y < F.y1;
+            }
+        }
+    }
+    hint_park(s_hint, t0, tile, F.hint_wgen, Hn, Hn->thr_min);
+    return in;
+}
+// The wave's wall time decides whether its tile is on the next frame's hard list (a tile that is hard stays hard down to 3/4 of
+// the threshold: the time of a wave depends on what runs beside it, and a tile at the threshold would change sides every frame).
+__device__ __forceinline__ void hint_finish(const uint32_t* s_hint) {
+    if ((threadIdx.x & 63u) != 0u) return;
+    const uint32_t tile_hard = s_hint[1];
+    if (tile_hard == 0xffffffffu) return;
+    const uint32_t cost = (uint32_t)__builtin_amdgcn_s_memrealtime() - s_hint[0];
+    if (cost < s_hint[5]) return;  // (nearly every wave)
+    const HintDev* __restrict__ Hn = reinterpret_cast<const HintDev*>((uintptr_t)s_hint[3] | ((uintptr_t)s_hint[4] << 32));
+    const bool hard = (tile_hard >> 31) != 0u;
+    const uint32_t tile = tile_hard & 0x7fffffffu, wgen = s_hint[2];
+    const bool wave16 = hard && Hn->per_tile == 4u;
+    uint32_t thr = wave16 ? Hn->thr_sparse : Hn->thr_dense;
+    if (hard) thr -= thr >> 2;
+    if (cost < thr) return;
+    const uint32_t wg = wgen << 16;
+    uint32_t* flag = Hn->flag_w + tile;
+    if (wave16) {  // four waves per tile: the first one that is long claims it
+        const uint32_t v = *flag;
+        if ((v >> 16) == wgen || atomicCAS(flag, v, wg | 0xffffu) != v) return;
+    }
+    const uint32_t i = atomicAdd(Hn->count_w, 1u);
+    if (i < Hn->cap) {
+        Hn->list_w[i] = tile;
+        *flag = wg | (i + 1u);
+    } else {
+        *flag = wg;  // the list is full: the tile stays a regular one
+    }
+}
+
 __device__ __forceinline__ bool tile_pixel(const FrameDev& F, int lane, int& x, int& y) {
     (void)lane;
     return tile_pixel_of(F, blockIdx.x, threadIdx.x, x, y);
