@@ -58,6 +58,18 @@ def host_cpus():
     return n
 
 
+def frame_hint_note(mode, rays_per_rank, world):
+    """What cgrt_set_frame_hints does to this launch (the library's policy restated: capi.cpp hint_mode_for)."""
+    eff = mode
+    if mode < 0:
+        eff = 2 if rays_per_rank <= 1_300_000 else (1 if rays_per_rank <= 2_600_000 and world > 1 else 0)
+    what = {0: "none (plain launch order)",
+            1: "the tiles whose wave took >= 45 us in the previous frame are traced first",
+            2: "the tiles whose wave took >= 45 us in the previous frame are traced as four 16-ray waves, first"}[eff]
+    return (f"cgrt_set_frame_hints({mode}): {what}" + ("" if eff == 0 else "; the first frame of a shape is plain; same pixels either way "
+            "(tests/test_frame_hints_gpu.py, profiles/r3_frame_hints.txt)"))
+
+
 def cpu_baseline(sd, cam, W, H, budget_s=12.0):
     """The oracle (CPU restatement of the reference algorithm, kind "port") timed on this box's host cores on a bounded
     sample of the same frame: a centred block of rows, run as one `omp parallel for` over rows exactly like
@@ -146,6 +158,8 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
                     help="auto: N = 1 -> the 1920x1080 headline frame, N > 1 -> strong (fixed 3840x2160 frame, BASELINE config 5)")
+    ap.add_argument("--frame-hints", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="cgrt_set_frame_hints: -1 the library's policy by frame size (default), 0 off, 1 hard tiles first, 2 hard tiles as 16-ray waves")
     ap.add_argument("--workload", choices=["primary", "shaded"], default="primary",
                     help="primary = fused ray generation + intersect (the headline); shaded = cgrt_render, depth 2, all rays of the frame")
     ap.add_argument("--walk", choices=["auto", "exact", "certified"], default="auto",
@@ -183,6 +197,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     pkg = entry.load_package()
+    pkg.set_frame_hints(args.frame_hints)
     from cg_raytracer_amd import tiling
 
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "headline")
@@ -321,6 +336,7 @@ def main():
                     "rays_entering_tree_rank0": cnt["tree_rays"],
                     "Mrays_per_s_over_rays_entering_tree_rank0": round(cnt["tree_rays"] / (kern_ms * 1e-3) / 1e6, 1),
                     "frames_in_flight": nfl,
+                    "frame_hints": frame_hint_note(args.frame_hints, per_rank[0] if isinstance(per_rank, (list, tuple)) else per_rank, world),
                     "rays_per_rank": per_rank,
                     "gather_ms_max_over_ranks": round(gather_max, 3),
                     "gather": "this rank's CgrtHit frame device -> pinned host, one async copy (not part of value)",

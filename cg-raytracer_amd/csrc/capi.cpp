@@ -1661,7 +1661,7 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
     // kernels stop at the counts they read on the device, and levels the previous frame did not reach are not issued.  The
     // counters come back once, behind the frame; if any list outgrew its grid, or a level that was not issued turns out to have
     // entries, the frame is drawn again the exact way below (first frames, resized frames and frames with spherical lights or
-    // work counters always are).  Same kernels on the same lists: the frame is bit-identical either way (tests/test_render_gpu.py).
+    // work counters always are).  Same kernels on the same lists: the frame is bit-identical either way (tests/test_render_prediction_gpu.py).
     bool frame_done = false;
     CgrtScene::RenderPred& P = s->rpred;
     const bool predictable = g_render_predict.load() && P.valid && P.W == W && P.H == H && P.rank == rank && P.nranks == nranks &&

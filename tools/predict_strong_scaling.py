@@ -13,6 +13,8 @@ from cg_raytracer_amd import tiling
 
 W, H = 3840, 2160
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+HINTS = int(os.environ.get("PREDICT_FRAME_HINTS", "-1"))  # cgrt_set_frame_hints: -1 = the library's default policy, 0 = off
+pkg.set_frame_hints(HINTS)
 sd = pkg.scenes.make_dragon(800_000)
 cam = pkg.scenes.default_camera(W, H)
 sc = pkg.Scene(sd)
@@ -39,4 +41,7 @@ for row in rows:
     row["predicted_speedup"] = round(base / row["predicted_ms_per_step"], 3)
     row["predicted_efficiency"] = round(base / row["predicted_ms_per_step"] / row["n_gpus"], 3)
 print(json.dumps({"what": "config 5 (3840x2160, 800K-triangle dragon stand-in) strong scaling PREDICTED from per-rank shares timed one at a time on one MI355X",
-                  "steps_per_share": K, "curve": rows}, indent=1))
+                  "steps_per_share": K,
+                  "frame_hints": {-1: "library default (cgrt_set_frame_hints -1): a share's frames after the first trace their hard tiles first (<= 2.6 M rays) "
+                                      "or as 16-ray waves (<= 1.3 M rays), from the previous frame's per-wave times; same pixels", 0: "off"}.get(HINTS, str(HINTS)),
+                  "curve": rows}, indent=1))
