@@ -268,3 +268,61 @@ def test_per_ray_driver_matches_oracle(pkg, orc, scene_data, name, W, H, level, 
     assert st["primary"] + st["shadow"] + st["reflection"] == nrays
     wave, _ = pkg.host_render(sd, cam, W, H, level)
     assert np.abs(rgb - wave).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_large_host_lists_go_through_the_bounce_buffers_unchanged(pkg, orc):
+    """Transfers above 1 MB take another road than small ones (capi.cpp lane_upload / lane_download: two alternating pinned 8 MB
+    buffers, pieces copied on several threads, and of a long list only the normals of rays that hit are copied back): a list of
+    700 K rays -- several pieces per buffer, a ragged last piece -- must come back exactly as its 20 K-ray slices do, HitInfo of a
+    miss untouched (the caller's normal stays), through the tree and through the brute force; and a whole 4 M-pixel frame's hits
+    and normals equal the same frame fetched in rectangles."""
+    sd = pkg.scenes.make_dragon(30_000)
+    sc = pkg.Scene(sd)
+    W, H = 1100, 640  # 704 000 rays: 22.5 MB of rays, 11.3 MB of hits, 8.4 MB of normals
+    cam = pkg.scenes.default_camera(W, H)
+    rays = sc.generate_rays(cam, W, H)
+    assert len(rays) * 28 > 2 * (8 << 20)
+    sentinel = np.float32(7.25)
+
+    def run(fn, sl):
+        hits = np.zeros(sl.stop - sl.start, pkg.HIT_DTYPE)
+        normals = np.full((sl.stop - sl.start, 3), sentinel, np.float32)
+        fn(rays[sl], hits, normals)
+        return hits, normals
+
+    def tree(r, hits, normals):
+        pkg._check(pkg.lib().cgrt_intersect_batch(sc._h, pkg._ptr(r), len(r), pkg._ptr(hits), pkg._ptr(normals)))
+
+    def brute(r, hits, normals):
+        pkg._check(pkg.lib().cgrt_intersect_brute_batch(sc._h, pkg._ptr(r), len(r), -1, pkg._ptr(hits), pkg._ptr(normals)))
+
+    whole_h, whole_n = run(tree, slice(0, len(rays)))
+    step = 20_000
+    for a in range(0, len(rays), step):
+        b = min(len(rays), a + step)
+        h, n = run(tree, slice(a, b))
+        assert h.tobytes() == whole_h[a:b].tobytes() and n.tobytes() == whole_n[a:b].tobytes(), a
+    miss = whole_h["hit"] == 0
+    assert miss.any() and (~miss).any()
+    assert (whole_n[miss] == sentinel).all() and not (whole_n[~miss] == sentinel).all(axis=1).any()
+    # against the oracle on a sample (the whole list would take the CPU a while)
+    pick = np.random.RandomState(3).choice(len(rays), 20_000, replace=False)
+    _assert_hits_equal(whole_h[pick], whole_n[pick], orc.OracleScene(sd).intersect(rays[pick]), "700 K-ray list through the bounce buffers")
+    # the brute force takes the same road (a shorter list: it tests every triangle)
+    nb = 90_000
+    bh, bn = run(brute, slice(0, nb))
+    for a in range(0, nb, 30_000):
+        h, n = run(brute, slice(a, a + 30_000))
+        assert h.tobytes() == bh[a : a + 30_000].tobytes() and n.tobytes() == bn[a : a + 30_000].tobytes(), a
+    # a frame: the whole-frame road (normals by hit flag) against rectangles (seeded on the device)
+    Wf, Hf = 2048, 2048
+    camf = pkg.scenes.default_camera(Wf, Hf)
+    fh, fn_ = sc.trace_primary(camf, Wf, Hf, want_normals=True)
+    for rect in ((0, 0, 1024, 1024), (1024, 0, 2048, 1024), (0, 1024, 2048, 2048)):
+        rh, rn = sc.trace_primary(camf, Wf, Hf, rect=rect, want_normals=True)
+        x0, y0, x1, y1 = rect
+        m = np.zeros((Hf, Wf), bool)
+        m[y0:y1, x0:x1] = True
+        m = m.ravel()
+        assert rh[m].tobytes() == fh[m].tobytes() and rn[m].tobytes() == fn_[m].tobytes(), rect
