@@ -4,9 +4,11 @@ tools/fuzz_render.py run here as library calls, ~45 s each, split over the commi
 every round appends one seed):
   * parity: random scenes (soups with degenerate / duplicated / axis-aligned triangles, slivers, dragon stand-ins, blobs, scales
     2^-20 .. 2^37) x ray families (tests/rayfam.py + vertex/edge-aimed rays); the default walk in BOTH kernel shapes, the exact walk
-    and the device brute force against the oracle on flag, t bits, primitive id, material id and normal bits;
+    and the device brute force against the oracle on flag, t bits, primitive id, material id and normal bits; and primary frames
+    with frame hints (hard tiles first / as 16-ray waves, thresholds of 20 .. 400 ticks) against the plain frame byte for byte;
   * render: cgrt_render (random scene, camera, 1-3 point lights, depth 0-4) against the oracle's recursive per-pixel driver:
-    RGB <= 1e-5 (BASELINE.json north_star's tolerance), equal ray counts, certified == exact == quad-shape frames byte for byte.
+    RGB <= 1e-5 (BASELINE.json north_star's tolerance), equal ray counts, certified == exact == quad-shape frames byte for byte
+    (the first frame of a scene is exactly sized, the later ones are predicted frames: capi.cpp render_impl).
 The fallback-ray count is asserted > 0 so that the path "no certificate -> exact walk" stays exercised."""
 import os
 import sys
@@ -42,7 +44,7 @@ def test_fuzz_parity_time_boxed(pkg, orc):
     print("fuzz parity:", tot)
     assert tot["mismatching_batches"] == 0, tot
     assert tot["scenes"] >= len(seeds) and tot["rays"] > 10_000
-    assert tot["certified_scenes"] > 0 and tot["quad_shape_batches"] > 0 and tot["tree_rays"] > 0
+    assert tot["certified_scenes"] > 0 and tot["quad_shape_batches"] > 0 and tot["tree_rays"] > 0 and tot["hinted_frames"] > 0
     assert tot["fallback_rays"] > 0, "the no-certificate -> exact-walk path must stay exercised"
 
 

@@ -48,7 +48,7 @@ def run(budget=120.0, seed0=1, verbose=True):
     """Fuzz for `budget` seconds from seed `seed0`; returns the statistics (mismatching_batches must be 0)."""
     t_end = time.time() + budget
     t_last = time.time()
-    stats = dict(scenes=0, rays=0, certified_scenes=0, fallback_rays=0, tree_rays=0, quad_shape_batches=0, mismatching_batches=0)
+    stats = dict(scenes=0, rays=0, certified_scenes=0, fallback_rays=0, tree_rays=0, quad_shape_batches=0, hinted_frames=0, mismatching_batches=0)
     it = 0
     while time.time() < t_end:
         rng = np.random.RandomState(seed0 * 100003 + it); it += 1
@@ -83,6 +83,22 @@ def run(budget=120.0, seed0=1, verbose=True):
             bad = bad or not same(hq, nq, ref)
             stats["quad_shape_batches"] += 1
             pkg.set_kernel_shape(-1)
+            # frame hints (cgrt_set_frame_hints): frames of one shape one after the other, hard tiles first / as 16-ray waves, with
+            # thresholds low enough that tiles are listed in frames this small -- the same bytes as the plain frame
+            Wf, Hf = int(rng.choice([64, 200, 333])), int(rng.choice([48, 120, 211]))
+            camf = np.asarray(pkg.scenes.default_camera(Wf, Hf), np.float32).copy(); camf[6] *= float(sc_)
+            camf[3:6] = rng.uniform(-3.0, 3.0, 3).astype(np.float32)
+            pkg.set_frame_hints(0)
+            f0 = sc.trace_primary(camf, Wf, Hf, want_normals=True)
+            pkg.debug_set_hint_thresholds(int(rng.choice([20, 100, 400])), int(rng.choice([20, 60, 200])))
+            for mode in (1, 2):
+                pkg.set_frame_hints(mode)
+                for _ in range(3):
+                    f = sc.trace_primary(camf, Wf, Hf, want_normals=True)
+                    bad = bad or f[0].tobytes() != f0[0].tobytes() or f[1].tobytes() != f0[1].tobytes()
+                    stats["hinted_frames"] += 1
+            pkg.set_frame_hints(-1)
+            pkg.debug_set_hint_thresholds(0, 0)
             sc.set_walk(False)
             h0, n0 = sc.intersect(R)
             bad = bad or not same(h0, n0, ref)
