@@ -35,7 +35,7 @@ pkg.set_frame_hints(0)
 print("no hints:", {n: t(W, H, r, k) for n, W, H, r, k in cases}, flush=True)
 for mode in ((1,) if os.environ.get("TUNE_MODE1") else (2,)):
     pkg.set_frame_hints(mode)
-    for dense, sparse in ((4000, 2200), (4500, 2500), (5000, 2700), (5000, 2700), (5500, 3000), (6000, 3300), (7000, 3800), (5000, 2000), (5000, 3500)):
+    for dense, sparse in ((4000, 2200), (4500, 2500), (4500, 2500), (5000, 2700), (5500, 3000), (3500, 2000)):
         pkg.debug_set_hint_thresholds(dense, sparse)
         print(f"mode {mode}, hard from {dense / 100:.0f} us (64-ray wave) / {sparse / 100:.0f} us (16-ray wave):", {n: t(W, H, r, k) for n, W, H, r, k in cases}, flush=True)
 pkg.debug_set_hint_thresholds(0, 0)
