@@ -1341,20 +1341,22 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
         const uint32_t cap = (uint32_t)std::min<uint64_t>(0xfffeu, std::max<uint64_t>(64, owned_tiles / 8));  // (a 40 us wave is rarer than that)
         const size_t set_words = (size_t)ntiles + cap + 16;  // flag | list | count (+ padding)
         const size_t bytes = 3 * set_words * 4 + 3 * 256;
+        // (hints are an accelerator: if their buffers cannot be had the frame is traced without them, it does not fail)
+        hipError_t e = hipSuccess;
         if (Hs.mem_bytes < bytes) {
             if (Hs.mem) (void)hipFree(Hs.mem);
             Hs.mem = nullptr;
             Hs.mem_bytes = 0;
-            HIP_TRY(hipMalloc(&Hs.mem, bytes));
-            Hs.mem_bytes = bytes;
+            e = hipMalloc(&Hs.mem, bytes);
+            if (e == hipSuccess) Hs.mem_bytes = bytes;
         }
-        HIP_TRY(hipMemsetAsync(Hs.mem, 0, bytes, stream));  // (generation 0 is never used: every flag is stale; on the launch's stream: ordered before it)
+        if (e == hipSuccess) e = hipMemsetAsync(Hs.mem, 0, bytes, stream);  // (generation 0 is never used: every flag is stale; on the launch's stream: ordered before it)
         uint32_t* base = static_cast<uint32_t*>(Hs.mem);
         char* structs = reinterpret_cast<char*>(base + 3 * set_words);
         auto flag = [&](int k) { return base + (size_t)k * set_words; };
         auto list = [&](int k) { return flag(k) + ntiles; };
         auto count = [&](int k) { return list(k) + cap; };
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < 3 && e == hipSuccess; p++) {
             HintDev h{};
             const int r = p, w = (p + 1) % 3, z = (p + 2) % 3;
             h.flag_r = flag(r), h.list_r = list(r), h.count_r = count(r);
@@ -1367,7 +1369,13 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
             h.thr_min = std::min(thr[0], thr[1]) - (std::min(thr[0], thr[1]) >> 2);
             Hs.phase[p] = reinterpret_cast<HintDev*>(structs + 256 * p);
             Hs.phase_host[p] = h;
-            HIP_TRY(hipMemcpyAsync(Hs.phase[p], &h, sizeof(h), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+            e = hipMemcpyAsync(Hs.phase[p], &h, sizeof(h), hipMemcpyHostToDevice, stream);  // (pageable source: staged before the call returns)
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            Hs.ready = false;
+            Hs.have_prev = false;
+            return CGRT_OK;
         }
         std::memcpy(Hs.key, key, sizeof(key));
         Hs.per_tile = per_tile;

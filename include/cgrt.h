@@ -18,7 +18,9 @@
  *     hipDeviceSynchronize once the pool has grown to the call sizes in use); cgrt_intersect_batch calls of at most 64 rays --
  *     BoundingVolumeHierarchy::intersect, one ray per call -- are COMBINED: concurrent callers append their rays to a shared
  *     pinned ring, one of them launches one kernel for all of them and everybody copies its own hits out (cgrt_set_call_combining);
- *   - the *_device entries only enqueue work on the caller's stream and touch no mutable scene state: concurrent too;
+ *   - the *_device entries only enqueue work on the caller's stream: concurrent too.  (cgrt_trace_primary_device keeps one piece of
+ *     per-scene state, the frame hints -- see cgrt_set_frame_hints: a short mutex while the launch is issued, and launches that
+ *     arrive on changing streams simply run without hints;)
  *   - cgrt_render* use one per-scene workspace: calls on the same scene are serialised by a mutex inside the library;
  *   - cgrt_set_* are process-wide options (mutex / atomic inside); cgrt_scene_set_walk and cgrt_scene_destroy must not
  *     race with calls on that scene.
