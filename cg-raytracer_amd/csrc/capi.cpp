@@ -183,6 +183,13 @@ struct CgrtScene {
         size_t mem_bytes = 0;
         HintDev* phase[3] = {nullptr, nullptr, nullptr};  // device addresses
         HintDev phase_host[3];        // what they hold
+        uint32_t* mailbox = nullptr;  // 64 pinned, device-mapped bytes: {generation, length of the list that frame read, threshold}
+        uint32_t* mailbox_dev = nullptr;
+        uint32_t seen_gen = 0;        // the last mailbox generation the host has looked at
+        uint32_t last_listed = 0;     // ... and what it said
+        bool heard = false;           // the mailbox has spoken since the buffers were (re)built
+        int empty_streak = 0;         // hinted frames in a row whose list was empty
+        int dormant = 0;              // frames still to run plain because of that
         uint64_t seq = 0;             // frames issued with these buffers
         bool have_prev = false;       // the set this frame would read was written by frame seq - 1
         hipStream_t last_stream = nullptr;
@@ -301,6 +308,7 @@ struct CgrtScene {
         (void)hipSetDevice(device);
         for (void* p : {d_records, d_leaves, d_tri_normals, d_spheres, d_materials, d_tri_leaf, d_paths, (void*)d_queues, hints.mem})
             if (p) (void)hipFree(p);
+        if (hints.mailbox) (void)hipHostFree(hints.mailbox);
         if (pin_frame) (void)hipHostFree(pin_frame);
         for (hipEvent_t e : {raux.spawned, raux.traced, raux.e0, raux.e1, raux.primary_done})
             if (e) (void)hipEventDestroy(e);
@@ -1273,13 +1281,18 @@ int cgrt_intersect_brute_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, in
     return CGRT_OK;
 }
 
-// Frame hints: which regime a frame is in goes by its size (profiles/r3_frame_hints.txt, dragon stand-in): frames of up to ~1.3 M
-// rays (960x540, a 1/8 share of the 4K frame) are as long as their longest wave -- their hard tiles are traced 16 rays per wave
-// (960x540 81 -> 63 us, the slowest 1/8 share 92 -> 79 us); a rank's share of up to ~2.6 M rays (a 1/4 share) gains from tracing
-// its hard tiles first in the usual 64-ray waves (118 -> 108 us); a whole frame of that size does not (1080p: 115.4 -> 118.2 us),
-// and larger frames gain nothing: no hints for them.  cgrt_set_frame_hints forces a mode; CGRT_FRAME_HINTS likewise (experiments).
+// Frame hints: which regime a frame is in goes by its size (profiles/r3_frame_hints.txt; six scenes -- the regular and the irregular
+// dragon stand-in, the 87 K dragon, dodgeColorTest, monkey, Cornell -- at eight frame shapes).  Frames of up to ~0.8 M rays (640x360,
+// 960x540, 800x800) are as long as their longest wave: their hard tiles are traced 16 rays per wave (0 .. -30 %, never more than
+// +3 %).  Around 1 M rays the outcome depends on the scene for whole frames and halves of frames (1280x720, half a 1080p frame:
+// -8 .. +7 %) -- no hints -- but a rank's share of a frame split over four or more GPUs still gains (1/8 of the 4K frame: -12 ..
+// +4 %); a 1/4 share (2 M rays) gains from tracing its hard tiles first in the usual 64-ray waves (-6 .. +2 %); a whole frame of
+// that size does not (1080p: +2 %), and larger frames gain nothing.  cgrt_set_frame_hints forces a mode; CGRT_FRAME_HINTS likewise.
 #ifndef CGRT_HINT_SPARSE_MAX_RAYS
-#define CGRT_HINT_SPARSE_MAX_RAYS 1300000ull
+#define CGRT_HINT_SPARSE_MAX_RAYS 800000ull
+#endif
+#ifndef CGRT_HINT_SPARSE_MAX_RAYS_SHARE
+#define CGRT_HINT_SPARSE_MAX_RAYS_SHARE 1300000ull  // a rank's share, four or more ranks
 #endif
 #ifndef CGRT_HINT_FIRST_MAX_RAYS
 #define CGRT_HINT_FIRST_MAX_RAYS 2600000ull
@@ -1288,7 +1301,7 @@ int cgrt_intersect_brute_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, in
 #define CGRT_HINT_THR_DENSE 4500u  // 45 us of s_memrealtime (swept: profiles/r3_frame_hints.txt)
 #endif
 #ifndef CGRT_HINT_THR_SPARSE
-#define CGRT_HINT_THR_SPARSE 2500u  // a 16-ray wave of a hard tile (64 hard rays: 97 us as one wave, 51 us as four)
+#define CGRT_HINT_THR_SPARSE 2500u  // (kept for cgrt_debug_set_hint_thresholds' second argument: a 16-ray wave counts from 5/9 of the threshold)
 #endif
 static int hint_mode_for(const FrameDev& F) {
     static const int env = [] {
@@ -1299,7 +1312,8 @@ static int hint_mode_for(const FrameDev& F) {
     if (m >= 0) return m > 2 ? 0 : m;
     const unsigned long long rays = owned_pixels(F);
     if (rays <= CGRT_HINT_SPARSE_MAX_RAYS) return 2;
-    if (rays <= CGRT_HINT_FIRST_MAX_RAYS && F.nranks > 1) return 1;
+    if (F.nranks >= 4 && rays <= CGRT_HINT_SPARSE_MAX_RAYS_SHARE) return 2;
+    if (F.nranks >= 4 && rays <= CGRT_HINT_FIRST_MAX_RAYS) return 1;
     return 0;
 }
 // Attaches the scene's hint buffers to F for ONE launch on `stream` (or leaves F without hints).  Called with s->hints.mu held
@@ -1338,12 +1352,17 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
         if (Hs.hint_stream_valid) (void)hipStreamSynchronize(Hs.hint_stream);
         (void)hipGetLastError();
         const uint64_t owned_tiles = (owned_pixels(F) + 63) / 64;
-        const uint32_t cap = (uint32_t)std::min<uint64_t>(0xfffeu, std::max<uint64_t>(64, owned_tiles / 8));  // (a 40 us wave is rarer than that)
+        // a list holds 4 % of the frame's tiles: the threshold keeps the listed share at 0.5 - 2 % (HintDev)
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(0xfffeu, std::max<uint64_t>(64, owned_tiles * 4 / 100));
         const size_t set_words = (size_t)ntiles + cap + 16;  // flag | list | count (+ padding)
-        const size_t bytes = 3 * set_words * 4 + 3 * 256;
+        const size_t bytes = 3 * set_words * 4 + 3 * 256 + 64;
         // (hints are an accelerator: if their buffers cannot be had the frame is traced without them, it does not fail)
         hipError_t e = hipSuccess;
-        if (Hs.mem_bytes < bytes) {
+        if (!Hs.mailbox) {
+            e = hipHostMalloc((void**)&Hs.mailbox, 64, hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&Hs.mailbox_dev, Hs.mailbox, 0);
+        }
+        if (e == hipSuccess && Hs.mem_bytes < bytes) {
             if (Hs.mem) (void)hipFree(Hs.mem);
             Hs.mem = nullptr;
             Hs.mem_bytes = 0;
@@ -1353,6 +1372,7 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
         if (e == hipSuccess) e = hipMemsetAsync(Hs.mem, 0, bytes, stream);  // (generation 0 is never used: every flag is stale; on the launch's stream: ordered before it)
         uint32_t* base = static_cast<uint32_t*>(Hs.mem);
         char* structs = reinterpret_cast<char*>(base + 3 * set_words);
+        uint32_t* ctl = reinterpret_cast<uint32_t*>(structs + 3 * 256);
         auto flag = [&](int k) { return base + (size_t)k * set_words; };
         auto list = [&](int k) { return flag(k) + ntiles; };
         auto count = [&](int k) { return list(k) + cap; };
@@ -1362,21 +1382,32 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
             h.flag_r = flag(r), h.list_r = list(r), h.count_r = count(r);
             h.flag_w = flag(w), h.list_w = list(w), h.count_w = count(w);
             h.count_z = count(z);
+            h.ctl = ctl;
+            h.mailbox = Hs.mailbox_dev;
             h.cap = cap;
             h.per_tile = (uint32_t)per_tile;
-            h.thr_dense = thr[0];
-            h.thr_sparse = thr[1];
-            h.thr_min = std::min(thr[0], thr[1]) - (std::min(thr[0], thr[1]) >> 2);
+            h.thr_floor = thr[0];
+            h.thr_ceil = thr[0] * 8u;
+            h.lo = (uint32_t)std::max<uint64_t>(1, owned_tiles / 200);
+            h.hi = (uint32_t)std::max<uint64_t>(4, owned_tiles * 2 / 100);
+            h.thr_min = (thr[0] * 5u / 9u) - ((thr[0] * 5u / 9u) >> 2);
             Hs.phase[p] = reinterpret_cast<HintDev*>(structs + 256 * p);
             Hs.phase_host[p] = h;
             e = hipMemcpyAsync(Hs.phase[p], &h, sizeof(h), hipMemcpyHostToDevice, stream);  // (pageable source: staged before the call returns)
         }
+        if (e == hipSuccess) e = hipMemcpyAsync(ctl, &thr[0], 4, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             Hs.ready = false;
             Hs.have_prev = false;
             return CGRT_OK;
         }
+        Hs.mailbox[0] = Hs.mailbox[1] = Hs.mailbox[2] = 0;
+        Hs.seen_gen = 0;
+        Hs.last_listed = 0;
+        Hs.heard = false;
+        Hs.empty_streak = 0;
+        Hs.dormant = 0;
         std::memcpy(Hs.key, key, sizeof(key));
         Hs.per_tile = per_tile;
         Hs.thr[0] = thr[0], Hs.thr[1] = thr[1];
@@ -1385,10 +1416,38 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
         Hs.have_prev = false;
         Hs.ready = true;
     }
+    // What the device has said about the lists so far (never waited for: the mailbox is a frame or two behind).
+    {
+        volatile uint32_t* mb = Hs.mailbox;
+        const uint32_t g = mb[0];
+        if (g != 0 && g != Hs.seen_gen) {
+            Hs.seen_gen = g;
+            Hs.last_listed = mb[1];
+            Hs.heard = true;
+            Hs.empty_streak = Hs.last_listed == 0 ? Hs.empty_streak + 1 : 0;
+        }
+    }
+    // A scene without long waves (a Cornell box, a small mesh) gains nothing and pays the mechanism (3-5 us per frame): after eight
+    // frames with empty lists the frames run plain for 56 launches, then the hints are tried again.
+    if (Hs.dormant > 0) {
+        Hs.dormant--;
+        Hs.have_prev = false;
+        return CGRT_OK;
+    }
+    if (Hs.empty_streak >= 8) {
+        Hs.empty_streak = 0;
+        Hs.dormant = 56;
+        Hs.have_prev = false;
+        return CGRT_OK;
+    }
     const uint64_t seq = Hs.seq++;
     auto gen_of = [](uint64_t q) { return (uint32_t)(q % 65535u) + 1u; };
     F.hint = Hs.phase[seq % 3];
-    F.hint_blocks = Hs.cap * (uint32_t)per_tile;
+    // the launch takes as many list entries as the last list the host has heard of held, and a quarter more (entries beyond are
+    // traced by their regular workgroups); all of the list's room while nothing has been heard
+    uint32_t entries = Hs.cap;
+    if (Hs.heard) entries = std::min<uint32_t>(Hs.cap, Hs.last_listed + Hs.last_listed / 4 + 32);
+    F.hint_blocks = entries * (uint32_t)per_tile;
     F.hint_rgen = Hs.have_prev ? gen_of(seq - 1) : 0u;
     F.hint_wgen = gen_of(seq);
     Hs.have_prev = true;

@@ -158,7 +158,7 @@ struct CameraDev {
 // the round-robin workgroup->XCD placement observed on MI355X) by ONE XCD, whose 4 MiB L2 then holds
 // that screen region's nodes and triangles instead of sharing every region with the 7 other L2s.
 // Placement is a speed matter only: results do not depend on it.
-// Frame hints (trace_kernels.hip "frame hints", capi.cpp FrameHints): what the previous frame of the same shape
+// Frame hints (walk_exact.h hinted_tile_pixel / hint_finish, capi.cpp FrameHints): what the previous frame of the same shape
 // learnt about its tiles, for the next one.  Every wave measures its own wall time; a wave that took long puts its 8x8 tile on the
 // frame's HARD LIST.  The next frame traces the tiles of that list FIRST (its first cap * per_tile workgroups; the regular
 // workgroups skip them) -- in the same 64-ray waves (per_tile = 1: the long waves no longer start in the frame's last round), or,
@@ -175,9 +175,18 @@ struct HintDev {  // one per rotation phase, resident in device memory
     uint32_t* list_w;
     uint32_t* count_w;
     uint32_t* count_z;       // the third set's counter, zeroed by this frame
+    uint32_t* ctl;           // shared by the phases: [0] the threshold in force (s_memrealtime ticks, 100 MHz, for a 64-ray wave)
+    uint32_t* mailbox;       // pinned host memory: {generation, length of the list this frame reads, threshold} -- what the host
+                             // learns about the lists without ever waiting for the device (capi.cpp attach_hints)
     uint32_t cap;            // tiles a list holds (<= 0xfffe)
     uint32_t per_tile;       // workgroups per hard tile: 1 or 4
-    uint32_t thr_dense, thr_sparse;  // s_memrealtime ticks (100 MHz) from which a 64-ray / 16-ray wave counts as hard
+    // The threshold follows the scene: how many tiles are worth treating specially is a matter of their SHARE of the frame (best
+    // at 0.5 - 5 % of the tiles, 0.5 - 2 % on every scene tried; from ~7 % on the frame gets slower: profiles/r3_frame_hints.txt), not of an absolute time -- 45 us
+    // lists 5 % of the regular stand-in's tiles at 960x540 and 17 % of the irregular one's at 800x800.  Workgroup 0 of every frame
+    // raises the threshold by 1/8 when the list it reads is longer than `hi` and lowers it by 1/16 (not below thr_floor) when it
+    // is shorter than `lo`.  A 16-ray wave counts as long from 5/9 of the threshold.
+    uint32_t thr_floor, thr_ceil;
+    uint32_t lo, hi;
     uint32_t thr_min;        // no wave faster than this can be hard: it ends without looking any further
 };
 
@@ -193,7 +202,9 @@ struct FrameDev {
     int packed;            // 1: results are written at blockIdx * block + threadIdx (the rank's pixels back to back, in the kernel's
                            // own order: one contiguous download per device) instead of at y * W + x
     const HintDev* hint;   // nullptr: no hints (the workgroups map to the tiles in launch order)
-    uint32_t hint_blocks;  // cap * per_tile workgroups in FRONT of the nblocks regular ones
+    uint32_t hint_blocks;  // workgroups in FRONT of the nblocks regular ones: per_tile for each of the hint_blocks / per_tile list entries this
+                           // launch can take (<= cap; sized from the last list length the host has heard of -- entries beyond are traced
+                           // by their regular workgroups)
     uint32_t hint_rgen;    // generation of the set to read (0: nothing to read -- a first frame still writes)
     uint32_t hint_wgen;    // generation this frame stamps on what it writes
 };

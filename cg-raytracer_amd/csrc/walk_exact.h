@@ -793,12 +793,29 @@ __device__ __forceinline__ bool hinted_tile_pixel(const FrameDev& F, int& x, int
     uint32_t b = blockIdx.x;
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    if (b == 0 && threadIdx.x == 0) *Hn->count_z = 0u;
-    const uint32_t cap = Hn->cap, per = Hn->per_tile;
-    uint32_t nh = 0;
+    const uint32_t per = Hn->per_tile;
+    const uint32_t cap = per == 4u ? (F.hint_blocks >> 2) : F.hint_blocks;  // entries this launch can take
+    uint32_t nh = 0, listed = 0;
     if (F.hint_rgen) {
-        nh = *Hn->count_r;
-        nh = nh < cap ? nh : cap;
+        listed = *Hn->count_r;
+        nh = listed < cap ? listed : cap;
+    }
+    if (b == 0 && threadIdx.x == 0) {
+        *Hn->count_z = 0u;
+        // the threshold follows the share of the tiles that was listed (HintDev), and the host hears about it
+        uint32_t thr = Hn->ctl[0];
+        if (F.hint_rgen) {
+            if (listed > Hn->hi)
+                thr = thr + (thr >> 3) < Hn->thr_ceil ? thr + (thr >> 3) : Hn->thr_ceil;
+            else if (listed < Hn->lo)
+                thr = thr - (thr >> 4) > Hn->thr_floor ? thr - (thr >> 4) : Hn->thr_floor;
+            Hn->ctl[0] = thr;
+        }
+        volatile uint32_t* mb = Hn->mailbox;
+        mb[1] = listed;
+        mb[2] = thr;
+        __threadfence_system();
+        mb[0] = F.hint_wgen;
     }
     const uint32_t ntiles = (uint32_t)F.tiles_x * (uint32_t)F.tiles_y;
     uint32_t tile = 0xffffffffu;
@@ -853,7 +870,8 @@ __device__ __forceinline__ void hint_finish(const uint32_t* s_hint) {
     const bool hard = (tile_hard >> 31) != 0u;
     const uint32_t tile = tile_hard & 0x7fffffffu, wgen = s_hint[2];
     const bool wave16 = hard && Hn->per_tile == 4u;
-    uint32_t thr = wave16 ? Hn->thr_sparse : Hn->thr_dense;
+    uint32_t thr = Hn->ctl[0];
+    if (wave16) thr = (thr * 5u) / 9u;  // a 16-ray wave of a listed tile (64 hard rays: 97 us as one wave, 51 us as four)
     if (hard) thr -= thr >> 2;
     if (cost < thr) return;
     const uint32_t wg = wgen << 16;

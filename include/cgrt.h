@@ -129,15 +129,18 @@ int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays);
 /* Frame hints of the primary frame entries (cgrt_trace_primary*, one scene, frames of one shape after another): every wave of a
  * frame measures its own wall time, and the 8x8 tiles whose wave took long are traced differently by the NEXT frame of the same
  * shape -- first (mode 1: the long waves no longer start in the frame's last round) or as four waves of 16 rays (mode 2: for
- * small frames, whose time is the time of their longest wave).  -1 (default) = by frame size (<= 1.3 M rays: 2; a rank's share of
- * <= 2.6 M rays: 1; anything else: none), 0 = off.  Only the order and the layout of the work change: every pixel is traced once, by the same arithmetic
+ * small frames, whose time is the time of their longest wave).  -1 (default) = by frame size (<= 0.8 M rays: 2; a rank's share
+ * of a frame split over >= 4 ranks: <= 1.3 M rays 2, <= 2.6 M rays 1; anything else: none), 0 = off.  The time from which a wave
+ * counts as long starts at 45 us and follows the scene (it rises while more than 2 % of the frame's tiles are listed); a scene
+ * whose lists stay empty is traced without hints for 56 of every 64 frames.  Only the order and the layout of the work change: every pixel is traced once, by the same arithmetic
  * (tested bit for bit); a first frame, a frame of another shape, the instrumented and the multi-device (packed) launches take no
  * hints.  The hint buffers belong to the scene: frames of one scene issued on ONE stream use them; when the caller changes
  * streams the library falls back to unhinted launches for a few frames (the *_device entries stay safe to call from several
  * threads, they are just not accelerated then).  Process-wide. */
 int cgrt_set_frame_hints(int mode);
 /* Tests: the wall time (s_memrealtime ticks, 100 MHz) from which a 64-ray / a 16-ray wave puts its tile on the hard list; 0 = the
- * defaults (4500 / 2500 = 45 / 25 us).  With a few ticks every tile that reaches the tree is "hard" and the lists overflow. */
+ * default (4500 = 45 us, the floor of the adaptive threshold; a 16-ray wave counts from 5/9 of the threshold in force, the second
+ * argument is ignored).  With a few ticks every tile that reaches the tree is "hard" and the lists overflow. */
 int cgrt_debug_set_hint_thresholds(unsigned dense_ticks, unsigned sparse_ticks);
 /* Diagnostics: the lengths of the scene's three rotating hard lists (synchronises the device). */
 int cgrt_debug_hint_counts(CgrtScene* scene, uint32_t* out3);

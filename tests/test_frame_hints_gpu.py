@@ -100,6 +100,22 @@ def test_hints_on_thin_leaf_scenes_and_every_walk(pkg, scene_data, hints):
                 assert h.tobytes() == h0.tobytes() and n.tobytes() == n0.tobytes(), (name, mode, k)
 
 
+def test_hints_go_dormant_and_come_back(pkg, scene_data, hints):
+    """A scene without long waves: after eight frames with empty lists the library traces 56 frames without hints, then probes
+    again (capi.cpp attach_hints) -- 150 frames cross that cycle twice; and a threshold that adapts (HintDev::ctl) while the camera
+    keeps moving."""
+    sd = scene_data("monkey")
+    W, H = 256, 192
+    sc, sc_ref = pkg.Scene(sd), pkg.Scene(sd)
+    hints(0)
+    cams = [_camera(pkg, W, H, yaw_deg=20.0 + 3.0 * (k % 7)) for k in range(7)]
+    refs = [sc_ref.trace_primary(c, W, H)[0].tobytes() for c in cams]
+    for mode in (2, 1, -1):
+        hints(mode)
+        for k in range(150):
+            assert sc.trace_primary(cams[k % 7], W, H)[0].tobytes() == refs[k % 7], (mode, k)
+
+
 def test_two_streams_taking_turns_and_threads_on_one_scene(pkg, hints):
     """The hint buffers belong to the scene and assume frames that follow each other on one stream; callers that alternate between
     streams, or several threads rendering the same scene at once, must still get the right pixels (the library then leaves the hints
