@@ -1395,7 +1395,8 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
             Hs.phase_host[p] = h;
             e = hipMemcpyAsync(Hs.phase[p], &h, sizeof(h), hipMemcpyHostToDevice, stream);  // (pageable source: staged before the call returns)
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(ctl, &thr[0], 4, hipMemcpyHostToDevice, stream);
+        const uint32_t thr_start = 2u * thr[0];  // (HintDev: from the side on which a frame is not slower than a plain one)
+        if (e == hipSuccess) e = hipMemcpyAsync(ctl, &thr_start, 4, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             Hs.ready = false;

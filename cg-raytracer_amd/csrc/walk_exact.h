@@ -805,10 +805,17 @@ __device__ __forceinline__ bool hinted_tile_pixel(const FrameDev& F, int& x, int
         // the threshold follows the share of the tiles that was listed (HintDev), and the host hears about it
         uint32_t thr = Hn->ctl[0];
         if (F.hint_rgen) {
-            if (listed > Hn->hi)
-                thr = thr + (thr >> 3) < Hn->thr_ceil ? thr + (thr >> 3) : Hn->thr_ceil;
+            uint32_t up = 0, down = 0;
+            if (listed > 2u * Hn->hi)
+                up = thr >> 2;
+            else if (listed > Hn->hi)
+                up = thr >> 3;
+            else if (2u * listed < Hn->lo)
+                down = thr >> 3;
             else if (listed < Hn->lo)
-                thr = thr - (thr >> 4) > Hn->thr_floor ? thr - (thr >> 4) : Hn->thr_floor;
+                down = thr >> 4;
+            thr = thr + up < Hn->thr_ceil ? thr + up : Hn->thr_ceil;
+            thr = thr - down > Hn->thr_floor ? thr - down : Hn->thr_floor;
             Hn->ctl[0] = thr;
         }
         volatile uint32_t* mb = Hn->mailbox;
