@@ -62,7 +62,7 @@ def frame_hint_note(mode, rays_per_rank, world):
     """What cgrt_set_frame_hints does to this launch (the library's policy restated: capi.cpp hint_mode_for)."""
     eff = mode
     if mode < 0:
-        eff = 2 if rays_per_rank <= 800_000 or (world >= 4 and rays_per_rank <= 1_300_000) else (1 if rays_per_rank <= 2_600_000 and world >= 4 else 0)
+        eff = 2 if rays_per_rank <= 800_000 or (world >= 4 and rays_per_rank <= 1_300_000) else 0
     what = {0: "none (plain launch order)",
             1: "the tiles whose wave took long in the previous frame (>= 45 us, rising while more than 2 % of the tiles qualify) are traced first",
             2: "the tiles whose wave took long in the previous frame (>= 45 us, rising while more than 2 % of the tiles qualify) are traced as four 16-ray waves, first"}[eff]

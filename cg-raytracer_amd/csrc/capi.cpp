@@ -1286,16 +1286,15 @@ int cgrt_intersect_brute_batch(CgrtScene* s, const CgrtRay* rays, uint64_t n, in
 // 960x540, 800x800) are as long as their longest wave: their hard tiles are traced 16 rays per wave (0 .. -30 %, never more than
 // +3 %).  Around 1 M rays the outcome depends on the scene for whole frames and halves of frames (1280x720, half a 1080p frame:
 // -8 .. +7 %) -- no hints -- but a rank's share of a frame split over four or more GPUs still gains (1/8 of the 4K frame: -12 ..
-// +4 %); a 1/4 share (2 M rays) gains from tracing its hard tiles first in the usual 64-ray waves (-6 .. +2 %); a whole frame of
-// that size does not (1080p: +2 %), and larger frames gain nothing.  cgrt_set_frame_hints forces a mode; CGRT_FRAME_HINTS likewise.
+// +5 %).  A 1/4 share (2 M rays) gains 2 - 6 % from tracing its hard tiles first in the usual 64-ray waves (mode 1) once the lists
+// have settled, but its first twenty-odd frames are slower than plain ones: mode 1 is there to be asked for, the policy does not
+// choose it.  A whole frame of that size does not gain (1080p: +2 %), larger frames gain nothing.  cgrt_set_frame_hints forces a
+// mode; CGRT_FRAME_HINTS likewise.
 #ifndef CGRT_HINT_SPARSE_MAX_RAYS
 #define CGRT_HINT_SPARSE_MAX_RAYS 800000ull
 #endif
 #ifndef CGRT_HINT_SPARSE_MAX_RAYS_SHARE
 #define CGRT_HINT_SPARSE_MAX_RAYS_SHARE 1300000ull  // a rank's share, four or more ranks
-#endif
-#ifndef CGRT_HINT_FIRST_MAX_RAYS
-#define CGRT_HINT_FIRST_MAX_RAYS 2600000ull
 #endif
 #ifndef CGRT_HINT_THR_DENSE
 #define CGRT_HINT_THR_DENSE 4500u  // 45 us of s_memrealtime (swept: profiles/r3_frame_hints.txt)
@@ -1313,8 +1312,7 @@ static int hint_mode_for(const FrameDev& F) {
     const unsigned long long rays = owned_pixels(F);
     if (rays <= CGRT_HINT_SPARSE_MAX_RAYS) return 2;
     if (F.nranks >= 4 && rays <= CGRT_HINT_SPARSE_MAX_RAYS_SHARE) return 2;
-    if (F.nranks >= 4 && rays <= CGRT_HINT_FIRST_MAX_RAYS) return 1;
-    return 0;
+    return 0;  // (mode 1 is never chosen: see above)
 }
 // Attaches the scene's hint buffers to F for ONE launch on `stream` (or leaves F without hints).  Called with s->hints.mu held
 // until the launch has been issued.  What keeps the buffers consistent: a frame reads the set the previous frame wrote, writes the
@@ -1395,7 +1393,7 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
             Hs.phase_host[p] = h;
             e = hipMemcpyAsync(Hs.phase[p], &h, sizeof(h), hipMemcpyHostToDevice, stream);  // (pageable source: staged before the call returns)
         }
-        const uint32_t thr_start = 2u * thr[0];  // (HintDev: from the side on which a frame is not slower than a plain one)
+        const uint32_t thr_start = thr[0] + thr[0] / 2;  // (HintDev: from the side on which a frame is not slower than a plain one)
         if (e == hipSuccess) e = hipMemcpyAsync(ctl, &thr_start, 4, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) {
             (void)hipGetLastError();

@@ -130,7 +130,7 @@ int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays);
  * frame measures its own wall time, and the 8x8 tiles whose wave took long are traced differently by the NEXT frame of the same
  * shape -- first (mode 1: the long waves no longer start in the frame's last round) or as four waves of 16 rays (mode 2: for
  * small frames, whose time is the time of their longest wave).  -1 (default) = by frame size (<= 0.8 M rays: 2; a rank's share
- * of a frame split over >= 4 ranks: <= 1.3 M rays 2, <= 2.6 M rays 1; anything else: none), 0 = off.  The time from which a wave
+ * of <= 1.3 M rays of a frame split over >= 4 ranks: 2; anything else: none -- mode 1 is only ever asked for), 0 = off.  The time from which a wave
  * counts as long starts at 45 us and follows the scene (it rises while more than 2 % of the frame's tiles are listed); a scene
  * whose lists stay empty is traced without hints for 56 of every 64 frames.  Only the order and the layout of the work change: every pixel is traced once, by the same arithmetic
  * (tested bit for bit); a first frame, a frame of another shape, the instrumented and the multi-device (packed) launches take no
