@@ -482,6 +482,23 @@ def main():
                 extras["dodgeColorTest_obj"]["meshes"] = int(sdd.nmesh)
                 extras["dodgeColorTest_obj"]["source"] = "reference data/dodgeColorTest.obj (the largest real mesh it ships), arrays committed as tests/golden/scenes/dodge.npz"
                 scd.close()
+            # the latency regime: small frames, and the slowest-looking share of config 5 split over 8 GPUs, traced
+            # on this one card -- without frame hints and with the library's default hints (cgrt_set_frame_hints; same pixels).  The
+            # hints' threshold settles over the first frames of a shape: 10 warm-up frames, then the timed ones.
+            def small(W_, H_, rank_, n_, mode):
+                pkg.set_frame_hints(mode)
+                st, _, _ = primary_runner(scene, pkg.scenes.default_camera(W_, H_), W_, H_, rank_, n_)
+                w_, k_ = timed(st, ksteps, 10)
+                return round(k_ * 1e3, 1)
+
+            lat = {}
+            for name, (W_, H_, r_, n_) in {"640x360": (640, 360, 0, 1), "960x540": (960, 540, 0, 1),
+                                           "one_eighth_of_3840x2160_rank0": (CONFIG5[0], CONFIG5[1], 0, 8)}.items():
+                lat[name] = {"kernel_us_no_hints": small(W_, H_, r_, n_, 0), "kernel_us_default_hints": small(W_, H_, r_, n_, -1)}
+            pkg.set_frame_hints(args.frame_hints)
+            lat["note"] = ("HIP events around back-to-back frames of one shape on one stream, dragon stand-in; default hints = the tiles whose wave "
+                           "was long in the previous frame are traced as four 16-ray waves (DESIGN.md 5.8, profiles/r3_frame_hints.txt)")
+            extras["latency_regime"] = lat
             out["extras"] = extras
         if not args.no_cpu_baseline:
             # N > 1: rank 0 alone, after the timed region's closing barrier (the other ranks wait at the final barrier below), so that
