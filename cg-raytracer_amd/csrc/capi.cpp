@@ -176,6 +176,8 @@ struct CgrtScene {
         std::mutex mu;
         bool ready = false;           // buffers allocated for `key`
         int key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // W, H, x0, y0, x1, y1, rank, nranks
+        int wanted[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the shape (+ mode, threshold) of the last launches that asked for other buffers
+        int wanted_count = 0;         // ... and how many in a row did
         int per_tile = 0;             // 1 / 4 (the policy the buffers were made for)
         unsigned thr[2] = {0, 0};     // the thresholds in the device structs
         uint32_t cap = 0;
@@ -1346,7 +1348,20 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
     const unsigned td = g_hint_thr_dense.load(), ts = g_hint_thr_sparse.load();
     const unsigned thr[2] = {td ? td : CGRT_HINT_THR_DENSE, ts ? ts : CGRT_HINT_THR_SPARSE};
     if (!Hs.ready || std::memcmp(key, Hs.key, sizeof(key)) != 0 || Hs.per_tile != per_tile || thr[0] != Hs.thr[0] || thr[1] != Hs.thr[1]) {
-        // (re)build the buffers: only when the frame's shape changes.  Whatever used the old ones must have finished.
+        // Other buffers are needed: the frame's shape has changed.  Rebuilding waits for whatever used the old ones, so it is only
+        // done for a shape that has been asked for four launches in a row -- a caller that alternates between shapes (two
+        // viewports, a tool that walks through the ranks) gets plain launches, not a host synchronisation per frame.
+        const int wanted[10] = {key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7], per_tile, (int)thr[0]};
+        if (std::memcmp(wanted, Hs.wanted, sizeof(wanted)) != 0) {
+            std::memcpy(Hs.wanted, wanted, sizeof(wanted));
+            Hs.wanted_count = 0;
+        }
+        if (++Hs.wanted_count < 4) {
+            Hs.have_prev = false;
+            return CGRT_OK;
+        }
+        Hs.wanted_count = 0;
+        // (re)build the buffers.  Whatever used the old ones must have finished.
         if (Hs.hint_stream_valid) (void)hipStreamSynchronize(Hs.hint_stream);
         (void)hipGetLastError();
         const uint64_t owned_tiles = (owned_pixels(F) + 63) / 64;

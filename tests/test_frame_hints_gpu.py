@@ -46,7 +46,8 @@ def test_hinted_frames_equal_plain_frames_and_the_oracle(pkg, orc, hints, mode, 
     ref = orc.OracleScene(sd).intersect(sc.generate_rays(cam, W, H))
     _assert_hits_equal(h0, n0, ref, "plain frame")
     hints(mode)
-    for k in range(6):  # frame 0 writes the first list, the others read one and write the next (three sets rotate)
+    for k in range(12):  # three plain frames (a shape gets its buffers at the fourth), one that writes the first list, then frames that
+        # read one list and write the next (three sets rotate)
         h, n = sc.trace_primary(cam, W, H, want_normals=True)
         assert h.tobytes() == h0.tobytes() and n.tobytes() == n0.tobytes(), (mode, k)
     # a rectangle and rank tiles: other shapes, new buffers, same pixels
@@ -55,13 +56,13 @@ def test_hinted_frames_equal_plain_frames_and_the_oracle(pkg, orc, hints, mode, 
     r0, _ = sc.trace_primary(cam, W, H, rect=rect)
     t0 = [sc.trace_primary(cam, W, H, rank=r, nranks=3)[0] for r in range(3)]
     hints(mode)
-    for k in range(4):
+    for k in range(9):
         assert sc.trace_primary(cam, W, H, rect=rect)[0].tobytes() == r0.tobytes(), k
     for k in range(3):
         for r in range(3):  # the shape changes with every call: hints restart each time, never a wrong pixel
             assert sc.trace_primary(cam, W, H, rank=r, nranks=3)[0].tobytes() == t0[r].tobytes(), (k, r)
     for r in range(3):
-        for k in range(4):  # and the same rank four times in a row: its hints are used
+        for k in range(9):  # and the same rank nine times in a row: its hints are used
             assert sc.trace_primary(cam, W, H, rank=r, nranks=3)[0].tobytes() == t0[r].tobytes(), (r, k)
 
 
@@ -95,7 +96,7 @@ def test_hints_on_thin_leaf_scenes_and_every_walk(pkg, scene_data, hints):
         h0, n0 = sc.trace_primary(cam, W, H, want_normals=True)
         for mode in (1, 2):
             hints(mode)
-            for k in range(4):
+            for k in range(9):
                 h, n = sc.trace_primary(cam, W, H, want_normals=True)
                 assert h.tobytes() == h0.tobytes() and n.tobytes() == n0.tobytes(), (name, mode, k)
 
@@ -149,7 +150,7 @@ def test_two_streams_taking_turns_and_threads_on_one_scene(pkg, hints):
         ok(hip.hipMemcpy(C.c_void_p(out.ctypes.data), bufs[i], C.c_size_t(nbytes), 2))  # device to host
         return out
 
-    order = [0, 0, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1]
+    order = [0] * 8 + [1, 0, 1] + [1] * 14 + [0] * 14 + [1]
     for k, i in enumerate(order):
         ok(hip.hipMemset(bufs[i], 0, C.c_size_t(nbytes)))
         ok(hip.hipDeviceSynchronize())
