@@ -1775,41 +1775,57 @@ static int render_impl(CgrtScene* s, const CgrtCamera* cam, int W, int H, const 
         HIP_TRY(launch_trace_primary_compact(s->dev, C, F, rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), ipix.as<int>(),
                                              pair, nullptr, nullptr, drgb.as<float>(), static_cast<const SpawnDev*>(dspawn.p)));
         const unsigned long long cap0 = cap_of(0);
-        HIP_TRY(hipEventRecord(aux.spawned, nullptr));
-        if (L)
-            HIP_TRY(launch_trace_shadow(s->dev, srays[0].as<float>(), sdist[0].as<float>(), cap0 * L, shits[0].as<CgrtHitDev>(), nullptr, pair,
-                                        nullptr, (unsigned long long)P.counts[0] * L, L));  // (hits x lights rays)
-        if (np >= 2) {  // level 0's mirror list and the whole of level 1 on the second stream, beside level 0's shadow list
+        // Level 0's two lists.  With a fast tree they go out as ONE launch (k_trace_pair: workgroups dealt alternately) and the whole
+        // frame stays on one stream; otherwise the shadow list runs on the default stream and the mirror list, with all of level 1
+        // behind it, on the second one.
+        const bool paired = np >= 2 && L > 0 && can_trace_pair(s->dev);
+        hipStream_t const side = paired ? nullptr : aux.s;  // where level 1 is evaluated
+        bool tail_on_aux = false;
+        if (paired) {
+            HIP_TRY(launch_trace_pair(s->dev, srays[0].as<float>(), sdist[0].as<float>(), cap0 * L, shits[0].as<CgrtHitDev>(), pair, L,
+                                      (unsigned long long)P.counts[0] * L, rays[1].as<float>(), cap_of(1), hits[1].as<CgrtHitDev>(), normals[1].as<float>(),
+                                      pair + 1, P.counts[1], nullptr));
+        } else {
+            HIP_TRY(hipEventRecord(aux.spawned, nullptr));
+            if (L)
+                HIP_TRY(launch_trace_shadow(s->dev, srays[0].as<float>(), sdist[0].as<float>(), cap0 * L, shits[0].as<CgrtHitDev>(), nullptr, pair,
+                                            nullptr, (unsigned long long)P.counts[0] * L, L));  // (hits x lights rays)
+        }
+        if (np >= 2) {  // level 1 (and, unpaired, level 0's mirror list in front of it)
             const unsigned long long cap1 = cap_of(1);
-            HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
-            HIP_TRY(launch_trace_batch(s->dev, rays[1].as<float>(), cap1, hits[1].as<CgrtHitDev>(), normals[1].as<float>(), nullptr, aux.s, pair + 1,
-                                       P.counts[1]));
+            if (!paired) {
+                HIP_TRY(hipStreamWaitEvent(aux.s, aux.spawned, 0));
+                HIP_TRY(launch_trace_batch(s->dev, rays[1].as<float>(), cap1, hits[1].as<CgrtHitDev>(), normals[1].as<float>(), nullptr, aux.s, pair + 1,
+                                           P.counts[1]));
+            }
             HIP_TRY(launch_spawn(rays[1].as<float>(), hits[1].as<CgrtHitDev>(), normals[1].as<float>(), pix[1].as<int>(), cap1, mats, dlights.as<float>(), L,
                                  2 < max_level, srays[1].as<float>(), sdist[1].as<float>(), sslot[1].as<int>(), lvl_of(1), rays[2].as<float>(),
-                                 pix[2].as<int>(), ctr_of(1), aux.s, pair + 1));
+                                 pix[2].as<int>(), ctr_of(1), side, pair + 1));
             if (L)
-                HIP_TRY(launch_trace_shadow(s->dev, srays[1].as<float>(), sdist[1].as<float>(), cap1 * L, shits[1].as<CgrtHitDev>(), aux.s, ctr_of(1) + 0,
+                HIP_TRY(launch_trace_shadow(s->dev, srays[1].as<float>(), sdist[1].as<float>(), cap1 * L, shits[1].as<CgrtHitDev>(), side, ctr_of(1) + 0,
                                             nullptr, (unsigned long long)P.counts[1] * L));
             HIP_TRY(launch_shade(rays[1].as<float>(), hits[1].as<CgrtHitDev>(), normals[1].as<float>(), shits[1].as<CgrtHitDev>(), sdist[1].as<float>(),
                                  sslot[1].as<int>(), cap1, mats, dlights.as<float>(), L, dslights.as<float>(), 0, dlit.as<uint32_t>(), Q.samples, lvl_of(1),
-                                 aux.s, pair + 1));
+                                 side, pair + 1));
             if (np >= 3)
-                HIP_TRY(launch_trace_batch(s->dev, rays[2].as<float>(), cap_of(2), hits[2].as<CgrtHitDev>(), normals[2].as<float>(), nullptr, aux.s,
+                HIP_TRY(launch_trace_batch(s->dev, rays[2].as<float>(), cap_of(2), hits[2].as<CgrtHitDev>(), normals[2].as<float>(), nullptr, side,
                                            ctr_of(1) + 1, P.counts[2]));
-            HIP_TRY(hipEventRecord(aux.traced, aux.s));
+            if (!paired) HIP_TRY(hipEventRecord(aux.traced, aux.s));
         }
         HIP_TRY(launch_shade(rays[0].as<float>(), hits[0].as<CgrtHitDev>(), normals[0].as<float>(), shits[0].as<CgrtHitDev>(), sdist[0].as<float>(),
                              sslot[0].as<int>(), cap0, mats, dlights.as<float>(), L, dslights.as<float>(), 0, dlit.as<uint32_t>(), Q.samples, lvl_of(0), nullptr,
                              pair));
-        // Two levels (the reference's depth, and most frames at any depth): the frame's last kernels are on the second stream, so
-        // the scatter into the frame goes there too, behind level 0's shading -- which finished long before -- instead of the
-        // default stream waiting for the second one (a cross-stream wait in front of the last kernel cost ~10 us of idle GPU).
-        const bool tail_on_aux = np == 2;
-        if (tail_on_aux) {
-            HIP_TRY(hipEventRecord(aux.primary_done, nullptr));  // (reused: level 0 is shaded)
-            HIP_TRY(hipStreamWaitEvent(aux.s, aux.primary_done, 0));
-        } else if (np >= 2) {
-            HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));
+        if (!paired) {
+            // Two levels (the reference's depth, and most frames at any depth): the frame's last kernels are on the second stream, so
+            // the scatter into the frame goes there too, behind level 0's shading -- which finished long before -- instead of the
+            // default stream waiting for the second one (a cross-stream wait in front of the last kernel cost ~10 us of idle GPU).
+            tail_on_aux = np == 2;
+            if (tail_on_aux) {
+                HIP_TRY(hipEventRecord(aux.primary_done, nullptr));  // (reused: level 0 is shaded)
+                HIP_TRY(hipStreamWaitEvent(aux.s, aux.primary_done, 0));
+            } else if (np >= 2) {
+                HIP_TRY(hipStreamWaitEvent(nullptr, aux.traced, 0));
+            }
         }
         hipStream_t const tail = tail_on_aux ? aux.s : nullptr;
         for (int level = 2; level < np; level++) {  // deeper levels: small, one after the other (buffer sets as in the exact path)

@@ -51,6 +51,12 @@ hipError_t launch_brute_batch(const SceneDev& S, const float* rays, unsigned lon
 hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float* dist, unsigned long long n, CgrtHitDev* hits, hipStream_t stream,
                                const uint32_t* dcount = nullptr, unsigned long long* counters = nullptr, unsigned long long expected = 0,
                                unsigned dmul = 1);  // dmul: the list holds *dcount x dmul rays
+// a level's shadow list (srays .. sexpected, as launch_trace_shadow) and its mirror list (rays .. expected, as launch_trace_batch) in ONE
+// launch, workgroups dealt alternately; can_trace_pair: the scene has a fast tree and the forced shape (if any) is a lane shape
+bool can_trace_pair(const SceneDev& S);
+hipError_t launch_trace_pair(const SceneDev& S, const float* srays, const float* sdist, unsigned long long ns, CgrtHitDev* shits, const uint32_t* sdcount,
+                             unsigned sdmul, unsigned long long sexpected, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
+                             const uint32_t* dcount, unsigned long long expected, hipStream_t stream);
 // *flag = value (system scope) once everything queued on the stream before it has finished
 hipError_t launch_signal(uint32_t* flag, uint32_t value, hipStream_t stream);
 hipError_t launch_generate_rays(const CameraDev& C, int W, int H, int x0, int y0, int x1, int y1, float* rays, hipStream_t stream);

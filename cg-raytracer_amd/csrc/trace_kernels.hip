@@ -185,6 +185,77 @@ __global__ CGRT_LB void k_trace_primary_compact(SceneDev S, CameraDev C, FrameDe
         }
     }
 }
+// Two lists in ONE launch: a level's shadow list (occlusion queries, k_trace_shadow's body) and its mirror list (closest hits,
+// k_trace_batch's body), workgroups dealt alternately so that both are on the chip at once.  A predicted frame (capi.cpp
+// render_impl) used to run them on two streams; the event that started the second stream and the wait that joined it again cost
+// ~17 us of an idle GPU per frame (profiles/r3_config3.txt) -- one launch on one stream needs neither.  Lane shapes only (64 or 16
+// rays per single-wave workgroup, by the host's estimate or on the device: see "kernel shape per launch").
+struct ListPairDev {
+    const float* rays_a;  // the shadow list
+    const float* dist_a;
+    CgrtHitDev* hits_a;
+    const uint32_t* dcount_a;
+    unsigned long long n_a;
+    unsigned dmul_a, rpw_a, adapt_a, blocks_a;
+    const float* rays_b;  // the mirror list
+    CgrtHitDev* hits_b;
+    float* normals_b;
+    const uint32_t* dcount_b;
+    unsigned long long n_b;
+    unsigned rpw_b, adapt_b, blocks_b;
+};
+template <bool FAST>
+__global__ CGRT_LB void k_trace_pair(SceneDev S, ListPairDev P) {
+    extern __shared__ uint32_t s_lds[];
+    const unsigned b = blockIdx.x, both = P.blocks_a < P.blocks_b ? P.blocks_a : P.blocks_b;
+    const bool is_a = b < 2u * both ? (b & 1u) == 0u : P.blocks_a > P.blocks_b;
+    const unsigned bid = b < 2u * both ? (b >> 1) : b - both;  // the workgroup's index within its list's launch
+    LaneCounters cnt;
+    if (is_a) {
+        unsigned long long n = P.n_a;
+        if (P.dcount_a) {
+            const unsigned long long present = (unsigned long long)*P.dcount_a * P.dmul_a;
+            n = present < n ? present : n;
+        }
+        unsigned rpw = P.rpw_a;
+        if (P.adapt_a) rpw = (n <= P.adapt_a) ? 16u : 64u;
+        const unsigned long long i = (unsigned long long)bid * rpw + threadIdx.x;
+        const bool active = i < n && threadIdx.x < rpw;
+        F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+        float t = 0.0f, qlen = 0.0f;
+        if (active) {
+            const float* r = P.rays_a + 7 * i;
+            o = f3(r[0], r[1], r[2]);
+            d = f3(r[3], r[4], r[5]);
+            t = r[6];
+            qlen = P.dist_a[i];
+        }
+        uint32_t hit_rec = REF_NONE;
+        walk_tree<false, FAST, WALK_OCCLUDED>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt, qlen);
+        if (active) finish_ray(S, o, d, t, hit_rec, P.hits_a + i, nullptr);
+    } else {
+        unsigned long long n = P.n_b;
+        if (P.dcount_b) {
+            const unsigned long long present = *P.dcount_b;
+            n = present < n ? present : n;
+        }
+        unsigned rpw = P.rpw_b;
+        if (P.adapt_b) rpw = (n <= P.adapt_b) ? 16u : 64u;
+        const unsigned long long i = (unsigned long long)bid * rpw + threadIdx.x;
+        const bool active = i < n && threadIdx.x < rpw;
+        F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+        float t = 0.0f;
+        if (active) {
+            const float* r = P.rays_b + 7 * i;
+            o = f3(r[0], r[1], r[2]);
+            d = f3(r[3], r[4], r[5]);
+            t = r[6];
+        }
+        uint32_t hit_rec = REF_NONE;
+        walk_tree<false, FAST>(S, active, o, d, t, hit_rec, CGRT_WAVE_STACK(s_lds), CGRT_WAVE_MAP(s_lds), cnt);
+        if (active) finish_ray(S, o, d, t, hit_rec, P.hits_b + i, P.normals_b ? P.normals_b + 3 * i : nullptr);
+    }
+}
 // rgb of every pixel this rank owns := 0 (main.cpp:293; the hits are written over it afterwards)
 __global__ __launch_bounds__(CGRT_BLOCK) void k_clear_owned(FrameDev F, float* __restrict__ rgb) {
     int x = 0, y = 0;
@@ -507,6 +578,28 @@ hipError_t launch_trace_shadow(const SceneDev& S, const float* rays, const float
         CGRT_LAUNCH2(k_trace_shadow, true, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt, dmul ? dmul : 1u);
     else
         CGRT_LAUNCH2(k_trace_shadow, false, fast, grid, block, stream, S, rays, dist, n, hits, dcount, counters, rpw, adapt, dmul ? dmul : 1u);
+    return hipGetLastError();
+}
+// The two lists of one level in one launch (k_trace_pair); false when the scene or the forced shape does not allow it -- the caller
+// then launches them one by one.
+bool can_trace_pair(const SceneDev& S) { return S.fast_root != REF_NONE && trace_block(S) == 64 && (shape_mode() == SHAPE_AUTO || shape_mode() == SHAPE_LANE64 || shape_mode() == SHAPE_LANE16); }
+hipError_t launch_trace_pair(const SceneDev& S, const float* srays, const float* sdist, unsigned long long ns, CgrtHitDev* shits, const uint32_t* sdcount,
+                             unsigned sdmul, unsigned long long sexpected, const float* rays, unsigned long long n, CgrtHitDev* hits, float* normals,
+                             const uint32_t* dcount, unsigned long long expected, hipStream_t stream) {
+    if (ns == 0 && n == 0) return hipSuccess;
+    auto lane_shape = [&](unsigned long long cap, unsigned long long exp_, const uint32_t* dc, unsigned& rpw, unsigned& adapt, unsigned& blocks) {
+        adapt = exp_ ? 0u : list_adapt_max(S, dc);
+        const int shape = adapt ? SHAPE_LANE64 : list_shape(S, exp_ ? exp_ : cap);
+        rpw = (shape == SHAPE_LANE64) ? 64u : 16u;  // (the quad shapes of a short list: 16 rays per wave here)
+        blocks = cap ? lane_grid(cap, 64u, rpw, adapt) : 0u;
+        if (adapt) rpw = 64u;
+    };
+    ListPairDev P{};
+    P.rays_a = srays, P.dist_a = sdist, P.hits_a = shits, P.dcount_a = sdcount, P.n_a = ns, P.dmul_a = sdmul ? sdmul : 1u;
+    lane_shape(ns, sexpected, sdcount, P.rpw_a, P.adapt_a, P.blocks_a);
+    P.rays_b = rays, P.hits_b = hits, P.normals_b = normals, P.dcount_b = dcount, P.n_b = n;
+    lane_shape(n, expected, dcount, P.rpw_b, P.adapt_b, P.blocks_b);
+    hipLaunchKernelGGL((k_trace_pair<true>), dim3(P.blocks_a + P.blocks_b), dim3(64), lds_bytes(64), stream, S, P);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary_compact(const SceneDev& S, const CameraDev& C, const FrameDev& F, float* rays, CgrtHitDev* hits, float* normals,
