@@ -1349,14 +1349,14 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
     const unsigned thr[2] = {td ? td : CGRT_HINT_THR_DENSE, ts ? ts : CGRT_HINT_THR_SPARSE};
     if (!Hs.ready || std::memcmp(key, Hs.key, sizeof(key)) != 0 || Hs.per_tile != per_tile || thr[0] != Hs.thr[0] || thr[1] != Hs.thr[1]) {
         // Other buffers are needed: the frame's shape has changed.  Rebuilding waits for whatever used the old ones, so it is only
-        // done for a shape that has been asked for four launches in a row -- a caller that alternates between shapes (two
+        // done for a shape that has been asked for three launches in a row -- a caller that alternates between shapes (two
         // viewports, a tool that walks through the ranks) gets plain launches, not a host synchronisation per frame.
         const int wanted[10] = {key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7], per_tile, (int)thr[0]};
         if (std::memcmp(wanted, Hs.wanted, sizeof(wanted)) != 0) {
             std::memcpy(Hs.wanted, wanted, sizeof(wanted));
             Hs.wanted_count = 0;
         }
-        if (++Hs.wanted_count < 4) {
+        if (++Hs.wanted_count < 3) {
             Hs.have_prev = false;
             return CGRT_OK;
         }

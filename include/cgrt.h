@@ -133,7 +133,7 @@ int cgrt_get_kernel_shape(int* mode, uint64_t* max_rays);
  * of <= 1.3 M rays of a frame split over >= 4 ranks: 2; anything else: none -- mode 1 is only ever asked for), 0 = off.  The time from which a wave
  * counts as long starts at 45 us and follows the scene (it rises while more than 2 % of the frame's tiles are listed); a scene
  * whose lists stay empty is traced without hints for 56 of every 64 frames.  Only the order and the layout of the work change: every pixel is traced once, by the same arithmetic
- * (tested bit for bit); the first frames of a shape (hints are set up for a shape that has been traced four times in a row), the
+ * (tested bit for bit); the first frames of a shape (hints are set up for a shape that has been traced three times in a row), the
  * instrumented and the multi-device (packed) launches take no hints.  The hint buffers belong to the scene: frames of one scene issued on ONE stream use them; when the caller changes
  * streams the library falls back to unhinted launches for a few frames (the *_device entries stay safe to call from several
  * threads, they are just not accelerated then).  Process-wide. */

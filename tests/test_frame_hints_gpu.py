@@ -46,7 +46,7 @@ def test_hinted_frames_equal_plain_frames_and_the_oracle(pkg, orc, hints, mode, 
     ref = orc.OracleScene(sd).intersect(sc.generate_rays(cam, W, H))
     _assert_hits_equal(h0, n0, ref, "plain frame")
     hints(mode)
-    for k in range(12):  # three plain frames (a shape gets its buffers at the fourth), one that writes the first list, then frames that
+    for k in range(12):  # two plain frames (a shape gets its buffers at the third), one that writes the first list, then frames that
         # read one list and write the next (three sets rotate)
         h, n = sc.trace_primary(cam, W, H, want_normals=True)
         assert h.tobytes() == h0.tobytes() and n.tobytes() == n0.tobytes(), (mode, k)

@@ -93,7 +93,7 @@ def run(budget=120.0, seed0=1, verbose=True):
             pkg.debug_set_hint_thresholds(int(rng.choice([20, 100, 400])), int(rng.choice([20, 60, 200])))
             for mode in (1, 2):
                 pkg.set_frame_hints(mode)
-                for _ in range(7):  # (a shape gets its hint buffers at the fourth frame in a row)
+                for _ in range(7):  # (a shape gets its hint buffers at the third frame in a row)
                     f = sc.trace_primary(camf, Wf, Hf, want_normals=True)
                     bad = bad or f[0].tobytes() != f0[0].tobytes() or f[1].tobytes() != f0[1].tobytes()
                     stats["hinted_frames"] += 1

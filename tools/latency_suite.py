@@ -22,7 +22,7 @@ sd = pkg.scenes.make_dragon(800_000)
 sc = pkg.Scene(sd)
 
 
-def ev_time(fn, k=K, warm=8):  # (frame hints are set up at a shape's fourth frame and settle over the next few)
+def ev_time(fn, k=K, warm=8):  # (frame hints are set up at a shape's third frame and settle over the next few)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

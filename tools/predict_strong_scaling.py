@@ -23,7 +23,7 @@ rows = []
 for n in (1, 2, 4, 8):
     shares = []
     for r in range(n):
-        for _ in range(8):  # (frame hints are set up at a shape's fourth frame and settle over the next few)
+        for _ in range(8):  # (frame hints are set up at a shape's third frame and settle over the next few)
             sc.trace_primary_device(cam, W, H, buf.data_ptr(), rank=r, nranks=n)
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
