@@ -189,7 +189,6 @@ struct CgrtScene {
         uint32_t* mailbox_dev = nullptr;
         uint32_t seen_gen = 0;        // the last mailbox generation the host has looked at
         uint32_t last_listed = 0;     // ... and what it said
-        bool heard = false;           // the mailbox has spoken since the buffers were (re)built
         int empty_streak = 0;         // hinted frames in a row whose list was empty
         int dormant = 0;              // frames still to run plain because of that
         uint64_t seq = 0;             // frames issued with these buffers
@@ -1419,7 +1418,6 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
         Hs.mailbox[0] = Hs.mailbox[1] = Hs.mailbox[2] = 0;
         Hs.seen_gen = 0;
         Hs.last_listed = 0;
-        Hs.heard = false;
         Hs.empty_streak = 0;
         Hs.dormant = 0;
         std::memcpy(Hs.key, key, sizeof(key));
@@ -1437,7 +1435,6 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
         if (g != 0 && g != Hs.seen_gen) {
             Hs.seen_gen = g;
             Hs.last_listed = mb[1];
-            Hs.heard = true;
             Hs.empty_streak = Hs.last_listed == 0 ? Hs.empty_streak + 1 : 0;
         }
     }
@@ -1457,10 +1454,10 @@ static int attach_hints(CgrtScene* s, FrameDev& F, hipStream_t stream) {
     const uint64_t seq = Hs.seq++;
     auto gen_of = [](uint64_t q) { return (uint32_t)(q % 65535u) + 1u; };
     F.hint = Hs.phase[seq % 3];
-    // the launch takes as many list entries as the last list the host has heard of held, and a quarter more (entries beyond are
-    // traced by their regular workgroups); all of the list's room while nothing has been heard
-    uint32_t entries = Hs.cap;
-    if (Hs.heard) entries = std::min<uint32_t>(Hs.cap, Hs.last_listed + Hs.last_listed / 4 + 32);
+    // The launch takes every entry the list has room for.  (Sizing it from the last list length heard of was tried: a caller that
+    // issues its frames back to back is dozens of launches ahead of the device, what it has heard is that much out of date -- a
+    // list length of 0 from a shape's first frame kept all those launches at 32 entries, and the hints did nothing for them.)
+    const uint32_t entries = Hs.cap;
     F.hint_blocks = entries * (uint32_t)per_tile;
     F.hint_rgen = Hs.have_prev ? gen_of(seq - 1) : 0u;
     F.hint_wgen = gen_of(seq);

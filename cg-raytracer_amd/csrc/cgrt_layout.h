@@ -203,8 +203,7 @@ struct FrameDev {
                            // own order: one contiguous download per device) instead of at y * W + x
     const HintDev* hint;   // nullptr: no hints (the workgroups map to the tiles in launch order)
     uint32_t hint_blocks;  // workgroups in FRONT of the nblocks regular ones: per_tile for each of the hint_blocks / per_tile list entries this
-                           // launch can take (<= cap; sized from the last list length the host has heard of -- entries beyond are traced
-                           // by their regular workgroups)
+                           // launch can take (<= cap; entries beyond are traced by their regular workgroups)
     uint32_t hint_rgen;    // generation of the set to read (0: nothing to read -- a first frame still writes)
     uint32_t hint_wgen;    // generation this frame stamps on what it writes
 };
